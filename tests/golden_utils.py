@@ -1,0 +1,169 @@
+"""Seeded weight / input generators shared by tools/make_golden.py (which feeds them to the
+reference's own modules, in the build container only) and the tests (which feed the same
+tensors to the oracle and to the HIP path).  Independent of the reference: pure torch CPU RNG,
+deterministic for a given torch build (the GPU box runs the same image)."""
+from __future__ import annotations
+
+import math
+from typing import Dict, Tuple
+
+import torch
+
+
+def _gen(shape, g, std=0.02, kind="normal"):
+    if kind == "normal":
+        return torch.randn(*shape, generator=g) * std
+    if kind == "ones":
+        return torch.ones(*shape) + torch.randn(*shape, generator=g) * 0.1
+    if kind == "small":
+        return torch.randn(*shape, generator=g) * 0.05
+    raise ValueError(kind)
+
+
+def vit_weights(D: int, depth: int, heads: int, hidden: int, patch: int, n_tok: int, seed: int,
+                prefix: str = "visual_encoder.") -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    sd[prefix + "cls_token"] = _gen((1, 1, D), g)
+    sd[prefix + "pos_embed"] = _gen((1, n_tok, D), g)
+    sd[prefix + "patch_embed.proj.weight"] = _gen((D, 3, patch, patch), g)
+    sd[prefix + "patch_embed.proj.bias"] = _gen((D,), g, kind="small")
+    for i in range(depth):
+        p = prefix + f"blocks.{i}."
+        sd[p + "norm1.weight"] = _gen((D,), g, kind="ones")
+        sd[p + "norm1.bias"] = _gen((D,), g, kind="small")
+        sd[p + "attn.q_bias"] = _gen((D,), g, kind="small")
+        sd[p + "attn.v_bias"] = _gen((D,), g, kind="small")
+        sd[p + "attn.qkv.weight"] = _gen((3 * D, D), g)
+        sd[p + "attn.proj.weight"] = _gen((D, D), g)
+        sd[p + "attn.proj.bias"] = _gen((D,), g, kind="small")
+        sd[p + "norm2.weight"] = _gen((D,), g, kind="ones")
+        sd[p + "norm2.bias"] = _gen((D,), g, kind="small")
+        sd[p + "mlp.fc1.weight"] = _gen((hidden, D), g)
+        sd[p + "mlp.fc1.bias"] = _gen((hidden,), g, kind="small")
+        sd[p + "mlp.fc2.weight"] = _gen((D, hidden), g)
+        sd[p + "mlp.fc2.bias"] = _gen((D,), g, kind="small")
+    return sd
+
+
+def qformer_weights(D: int, layers: int, inter: int, enc_w: int, seed: int, cross_freq: int = 2,
+                    prefix: str = "Qformer.bert.", std: float = 0.02) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    sd[prefix + "embeddings.LayerNorm.weight"] = _gen((D,), g, kind="ones")
+    sd[prefix + "embeddings.LayerNorm.bias"] = _gen((D,), g, kind="small")
+
+    def attn(p, kv_w):
+        sd[p + "self.query.weight"] = _gen((D, D), g, std)
+        sd[p + "self.query.bias"] = _gen((D,), g, kind="small")
+        sd[p + "self.key.weight"] = _gen((D, kv_w), g, std)
+        sd[p + "self.key.bias"] = _gen((D,), g, kind="small")
+        sd[p + "self.value.weight"] = _gen((D, kv_w), g, std)
+        sd[p + "self.value.bias"] = _gen((D,), g, kind="small")
+        sd[p + "output.dense.weight"] = _gen((D, D), g, std)
+        sd[p + "output.dense.bias"] = _gen((D,), g, kind="small")
+        sd[p + "output.LayerNorm.weight"] = _gen((D,), g, kind="ones")
+        sd[p + "output.LayerNorm.bias"] = _gen((D,), g, kind="small")
+
+    for i in range(layers):
+        p = prefix + f"encoder.layer.{i}."
+        attn(p + "attention.", D)
+        if i % cross_freq == 0:
+            attn(p + "crossattention.", enc_w)
+        sd[p + "intermediate_query.dense.weight"] = _gen((inter, D), g, std)
+        sd[p + "intermediate_query.dense.bias"] = _gen((inter,), g, kind="small")
+        sd[p + "output_query.dense.weight"] = _gen((D, inter), g, std)
+        sd[p + "output_query.dense.bias"] = _gen((D,), g, kind="small")
+        sd[p + "output_query.LayerNorm.weight"] = _gen((D,), g, kind="ones")
+        sd[p + "output_query.LayerNorm.bias"] = _gen((D,), g, kind="small")
+    return sd
+
+
+def llama_weights(D: int, layers: int, inter: int, vocab: int, seed: int, prefix: str = "llama_model.",
+                  std: float = 0.02, lora_r: int = 0) -> Dict[str, torch.Tensor]:
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    sd[prefix + "model.embed_tokens.weight"] = _gen((vocab, D), g, std)
+    for i in range(layers):
+        p = prefix + f"model.layers.{i}."
+        for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+            sd[p + f"self_attn.{n}.weight"] = _gen((D, D), g, std)
+        sd[p + "mlp.gate_proj.weight"] = _gen((inter, D), g, std)
+        sd[p + "mlp.down_proj.weight"] = _gen((D, inter), g, std)
+        sd[p + "mlp.up_proj.weight"] = _gen((inter, D), g, std)
+        sd[p + "input_layernorm.weight"] = _gen((D,), g, kind="ones")
+        sd[p + "post_attention_layernorm.weight"] = _gen((D,), g, kind="ones")
+        if lora_r:
+            for n in ("q_proj", "v_proj"):
+                sd[p + f"self_attn.{n}.lora_A.default.weight"] = _gen((lora_r, D), g, std)
+                sd[p + f"self_attn.{n}.lora_B.default.weight"] = _gen((D, lora_r), g, std)
+    sd[prefix + "model.norm.weight"] = _gen((D,), g, kind="ones")
+    sd[prefix + "lm_head.weight"] = _gen((vocab, D), g, std)
+    return sd
+
+
+def ve_stem_weights(prefix: str, g, sd, dim_in: int = 1):
+    c = dim_in
+    for idx in (0, 3, 6, 9, 12):
+        co = c * 4
+        bound = 1.0 / math.sqrt(c * 9)
+        sd[prefix + f"meta_net.{idx}.weight"] = (torch.rand(co, c, 3, 3, generator=g) * 2 - 1) * bound
+        sd[prefix + f"meta_net.{idx}.bias"] = (torch.rand(co, generator=g) * 2 - 1) * bound
+        c = co
+    return c
+
+
+def adapter_weights(seed: int, D_vit: int = 1408, rank: int = 4, d_q: int = 768, d_llm: int = 4096,
+                    with_tokenizer: bool = True, with_instructor: bool = True) -> Dict[str, torch.Tensor]:
+    """expert_adaptor + VEInstructor + VETokenizer weights (reference init distributions:
+    networks.py:78-79 N(0,.02); conv default kaiming-uniform bound 1/sqrt(fan_in); base_prompts N(0,1))."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    sd["expert_adaptor.conv1.weight"] = _gen((rank, D_vit), g)
+    sd["expert_adaptor.conv2.weight"] = _gen((D_vit, rank), g)
+    if with_instructor:
+        c = ve_stem_weights("VEInstructor.", g, sd)
+        bound = 1.0 / math.sqrt(c)
+        sd["VEInstructor.meta_net.15.weight"] = (torch.rand(d_q, c, 1, 1, generator=g) * 2 - 1) * bound
+        sd["VEInstructor.meta_net.15.bias"] = (torch.rand(d_q, generator=g) * 2 - 1) * bound
+    if with_tokenizer:
+        c = ve_stem_weights("VETokenizer.", g, sd)
+        bound = 1.0 / math.sqrt(c * 25)
+        sd["VETokenizer.meta_net.15.weight"] = (torch.rand(d_llm, c, 5, 5, generator=g) * 2 - 1) * bound
+        sd["VETokenizer.meta_net.15.bias"] = (torch.rand(d_llm, generator=g) * 2 - 1) * bound
+        sd["VETokenizer.base_prompts"] = torch.randn(9, d_llm, generator=g)
+    return sd
+
+
+def glue_weights(seed: int, n_query: int = 32, d_q: int = 768, D_vit: int = 1408, d_llm: int = 4096):
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    sd["query_tokens"] = _gen((1, n_query, d_q), g)
+    sd["ln_vision.weight"] = _gen((D_vit,), g, kind="ones")
+    sd["ln_vision.bias"] = _gen((D_vit,), g, kind="small")
+    sd["llama_proj.weight"] = _gen((d_llm, d_q), g)
+    sd["llama_proj.bias"] = _gen((d_llm,), g, kind="small")
+    return sd
+
+
+def synthetic_batch(B: int, vocab: int, seed: int, n_before: int = 4, n_after: int = 28, n_tgt: int = 16,
+                    img: int = 224, pad_tail: int = 0):
+    """SURVEY 8(d) synthetic inputs: image N(0,1), maps U[0,1), ids uniform in [3, V)."""
+    g = torch.Generator().manual_seed(seed)
+    image = torch.randn(B, 3, img, img, generator=g)
+    maps = torch.rand(B, 1, 224, 224, generator=g)
+    before = torch.randint(3, vocab, (B, n_before), generator=g)
+    after = torch.randint(3, vocab, (B, n_after), generator=g)
+    # prompts are identical across the batch in the reference (one fixed question string)
+    before = before[:1].expand(B, -1).contiguous()
+    after = after[:1].expand(B, -1).contiguous()
+    tgt = torch.randint(3, vocab, (B, n_tgt), generator=g)
+    mask = torch.ones(B, n_tgt, dtype=torch.long)
+    if pad_tail:
+        # ragged targets: row b loses (b % (pad_tail+1)) trailing tokens (right padding, pad id 2)
+        for b in range(B):
+            k = b % (pad_tail + 1)
+            if k:
+                tgt[b, -k:] = 2
+                mask[b, -k:] = 0
+    return image, maps, before, after, tgt, mask

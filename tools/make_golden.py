@@ -1,0 +1,451 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by running the REFERENCE's own modules (build container only).
+
+The reference tree (/root/reference) is imported here, by file path, with the import shims
+listed in SURVEY.md section 8(c); nothing of it is copied.  The fixtures hold only data: seeds /
+small inputs and the reference's outputs (loss, logits, activations, gradients, greedy ids).
+Weights are regenerated from seeds by tests/golden_utils.py on both sides, so large weights are
+never committed.
+
+Usage:  python tools/make_golden.py [--ref /root/reference] [--only NAME]
+"""
+from __future__ import annotations
+
+import argparse
+import importlib.util
+import os
+import sys
+import types
+from functools import partial
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from tests import golden_utils as gu  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+# --------------------------------------------------------------------------- #
+# reference loaders (shims per SURVEY 8c)                                      #
+# --------------------------------------------------------------------------- #
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def load_reference(ref):
+    mods = {}
+    mods["llama"] = _load(os.path.join(ref, "minigpt4/models/modeling_llama.py"), "ref_modeling_llama")
+    mods["networks"] = _load(os.path.join(ref, "minigpt4/models/networks.py"), "ref_networks")
+    # eva_vit: stub timm + minigpt4.common.dist_utils
+    timm = types.ModuleType("timm")
+    tm = types.ModuleType("timm.models")
+    tl = types.ModuleType("timm.models.layers")
+    tl.drop_path = lambda x, p=0.0, training=False: x
+    tl.to_2tuple = lambda x: x if isinstance(x, tuple) else (x, x)
+    tl.trunc_normal_ = torch.nn.init.trunc_normal_
+    tr = types.ModuleType("timm.models.registry")
+    tr.register_model = lambda f: f
+    sys.modules.update({"timm": timm, "timm.models": tm, "timm.models.layers": tl, "timm.models.registry": tr})
+    mg = types.ModuleType("minigpt4")
+    mgc = types.ModuleType("minigpt4.common")
+    mgd = types.ModuleType("minigpt4.common.dist_utils")
+    mgd.download_cached_file = lambda *a, **k: None
+    mgr = types.ModuleType("minigpt4.common.registry")
+
+    class _Reg:
+        def __getattr__(self, name):
+            return lambda *a, **k: (lambda c: c)
+
+    mgr.registry = _Reg()
+    sys.modules.update({"minigpt4": mg, "minigpt4.common": mgc, "minigpt4.common.dist_utils": mgd,
+                        "minigpt4.common.registry": mgr})
+    mods["eva_vit"] = _load(os.path.join(ref, "minigpt4/models/eva_vit.py"), "ref_eva_vit")
+    mods["optims"] = _load(os.path.join(ref, "minigpt4/common/optims.py"), "ref_optims")
+    # Qformer: transformers.modeling_utils shims
+    import transformers.modeling_utils as mu
+    import transformers.pytorch_utils as pu
+    mu.apply_chunking_to_forward = pu.apply_chunking_to_forward
+    mu.prune_linear_layer = pu.prune_linear_layer
+    mu.find_pruneable_heads_and_indices = lambda *a, **k: (set(), None)
+    mods["qformer"] = _load(os.path.join(ref, "minigpt4/models/Qformer.py"), "ref_qformer")
+    Q = mods["qformer"]
+    Q.BertPreTrainedModel.init_weights = lambda self: self.apply(self._init_weights)
+    Q.BertPreTrainedModel.get_head_mask = lambda self, hm, n, *a: [None] * n
+    return mods
+
+
+def ref_vit(M, D, depth, heads, mlp_ratio, img, patch=14):
+    return M["eva_vit"].VisionTransformer(
+        img_size=img, patch_size=patch, use_mean_pooling=False, embed_dim=D, depth=depth, num_heads=heads,
+        mlp_ratio=mlp_ratio, qkv_bias=True, drop_path_rate=0.0, norm_layer=partial(nn.LayerNorm, eps=1e-6)).eval()
+
+
+def ref_qformer(M, D, layers, heads, inter, enc_w, n_q):
+    from transformers import BertConfig
+    cfg = BertConfig(hidden_size=D, num_hidden_layers=layers, num_attention_heads=heads, intermediate_size=inter,
+                     hidden_act="gelu", layer_norm_eps=1e-12, hidden_dropout_prob=0.1,
+                     attention_probs_dropout_prob=0.1, vocab_size=30522, max_position_embeddings=512)
+    cfg.encoder_width = enc_w
+    cfg.add_cross_attention = True
+    cfg.cross_attention_freq = 2
+    cfg.query_length = n_q
+    q = M["qformer"].BertLMHeadModel(config=cfg)
+    # runtime surgery of myriad.py:151-156
+    q.cls = None
+    q.bert.embeddings.word_embeddings = None
+    q.bert.embeddings.position_embeddings = None
+    for layer in q.bert.encoder.layer:
+        layer.output = None
+        layer.intermediate = None
+    return q.eval()
+
+
+def ref_llama(M, D, layers, heads, inter, vocab):
+    from transformers.models.llama.configuration_llama import LlamaConfig
+    cfg = LlamaConfig(vocab_size=vocab, hidden_size=D, intermediate_size=inter, num_hidden_layers=layers,
+                      num_attention_heads=heads, rms_norm_eps=1e-6, hidden_act="silu",
+                      max_position_embeddings=2048, pad_token_id=0, bos_token_id=1, eos_token_id=2)
+    return M["llama"].LlamaForCausalLM(cfg).eval()
+
+
+def load_sd(module, sd, prefix):
+    sub = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    missing, unexpected = module.load_state_dict(sub, strict=False)
+    bad = [m for m in missing if "inv_freq" not in m and "position_ids" not in m]
+    assert not bad, f"missing {bad[:5]}"
+    assert not unexpected, f"unexpected {unexpected[:5]}"
+
+
+def save(name, **arrs):
+    os.makedirs(OUT, exist_ok=True)
+    conv = {}
+    for k, v in arrs.items():
+        if isinstance(v, torch.Tensor):
+            v = v.detach().cpu().numpy()
+        conv[k] = np.asarray(v)
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **conv)
+    print(f"wrote {path}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+# --------------------------------------------------------------------------- #
+# cases                                                                        #
+# --------------------------------------------------------------------------- #
+def case_vit(M):
+    # tiny full pipeline: D=64, 2 blocks, 4 heads, img 56 (16 patches + cls)
+    D, depth, heads, img = 64, 2, 4, 56
+    hidden = int(D * 4.3637)
+    sd = gu.vit_weights(D, depth, heads, hidden, 14, 17, seed=101)
+    m = ref_vit(M, D, depth, heads, 4.3637, img)
+    load_sd(m, sd, "visual_encoder.")
+    x = torch.randn(2, 3, img, img, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        y = m(x)
+    save("vit_tiny", image=x, out=y, meta=np.array([D, depth, heads, hidden, img, 101]))
+    # full width, 1 block, head_dim 88
+    D, depth, heads, img = 1408, 1, 16, 224
+    hidden = int(D * 4.3637)
+    sd = gu.vit_weights(D, depth, heads, hidden, 14, 257, seed=102)
+    m = ref_vit(M, D, depth, heads, 4.3637, img)
+    load_sd(m, sd, "visual_encoder.")
+    x = torch.randn(1, 3, img, img, generator=torch.Generator().manual_seed(6))
+    with torch.no_grad():
+        y = m(x)
+    save("vit_fullwidth", image_seed=np.array([6]), out_sub=y[:, ::8, ::4], out_mean=y.mean(), out_std=y.std(),
+         meta=np.array([D, depth, heads, hidden, img, 102]))
+
+
+def case_networks(M):
+    N = M["networks"]
+    sd = gu.adapter_weights(seed=201)
+    ad = N.LoraAdaptorV2(dims=1408, input_dim=4)
+    load_sd(ad, sd, "expert_adaptor.")
+    ins = N.VEInstructorV2()
+    load_sd(ins, sd, "VEInstructor.")
+    tok = N.VETokenizer()
+    load_sd(tok, sd, "VETokenizer.")
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(2, 257, 1408, generator=g, requires_grad=True)
+    maps = torch.rand(2, 1, 224, 224, generator=g)
+    ct_a = torch.randn(2, 257, 1408, generator=g)
+    ct_i = torch.randn(2, 49, 768, generator=g)
+    ct_t = torch.randn(2, 18, 4096, generator=g)
+    ya = ad(x)
+    yi = ins(maps)
+    yt = tok(maps)
+    ((ya * ct_a).sum() + (yi * ct_i).sum() + (yt * ct_t).sum()).backward()
+    out = dict(x=x.detach()[:, ::16], seed=np.array([201, 7]), adaptor_out_sub=ya[:, ::16, ::8],
+               instr_out=yi, tok_out_sub=yt[:, :, ::8], dx_sub=x.grad[:, ::16, ::8],
+               dA=ad.conv1.weight.grad, dB=ad.conv2.weight.grad)
+    for nm, mod in (("instr", ins), ("tok", tok)):
+        for idx in (0, 3, 6, 9, 12, 15):
+            w = mod.meta_net[idx].weight.grad
+            b = mod.meta_net[idx].bias.grad
+            out[f"{nm}_dw{idx}_norm"] = w.norm()
+            out[f"{nm}_dw{idx}_sub"] = w.reshape(w.shape[0], -1)[:8, :32]
+            out[f"{nm}_db{idx}"] = b[:64]
+    out["tok_dbase"] = tok.base_prompts.grad[:, ::64]
+    save("networks_full", **out)
+
+
+def case_qformer(M):
+    # tiny
+    D, layers, heads, inter, enc_w, n_q, n_enc = 64, 4, 4, 128, 48, 8, 10
+    sd = gu.qformer_weights(D, layers, inter, enc_w, seed=301)
+    q = ref_qformer(M, D, layers, heads, inter, enc_w, n_q)
+    load_sd(q.bert, sd, "Qformer.bert.")
+    g = torch.Generator().manual_seed(8)
+    qe = torch.randn(2, n_q, D, generator=g, requires_grad=True)
+    enc = torch.randn(2, n_enc, enc_w, generator=g, requires_grad=True)
+    ct = torch.randn(2, n_q, D, generator=g)
+    atts = torch.ones(2, n_enc, dtype=torch.long)
+    y = q.bert(query_embeds=qe, encoder_hidden_states=enc, encoder_attention_mask=atts, return_dict=True).last_hidden_state
+    (y * ct).sum().backward()
+    save("qformer_tiny", query=qe.detach(), enc=enc.detach(), ct=ct, out=y, dquery=qe.grad, denc=enc.grad,
+         meta=np.array([D, layers, heads, inter, enc_w, 301]))
+    # full width, 2 layers (one with cross-attn), 81 queries x 257 image tokens
+    D, layers, heads, inter, enc_w, n_q, n_enc = 768, 2, 12, 3072, 1408, 81, 257
+    sd = gu.qformer_weights(D, layers, inter, enc_w, seed=302)
+    q = ref_qformer(M, D, layers, heads, inter, enc_w, 32)
+    load_sd(q.bert, sd, "Qformer.bert.")
+    g = torch.Generator().manual_seed(9)
+    qe = torch.randn(1, n_q, D, generator=g, requires_grad=True)
+    enc = torch.randn(1, n_enc, enc_w, generator=g, requires_grad=True)
+    ct = torch.randn(1, n_q, D, generator=g)
+    y = q.bert(query_embeds=qe, encoder_hidden_states=enc, encoder_attention_mask=torch.ones(1, n_enc, dtype=torch.long),
+               return_dict=True).last_hidden_state
+    (y * ct).sum().backward()
+    save("qformer_fullwidth", seed=np.array([302, 9]), out_sub=y[:, :, ::4], dquery_sub=qe.grad[:, :, ::4],
+         denc_sub=enc.grad[:, ::4, ::8], meta=np.array([D, layers, heads, inter, enc_w, 302]))
+
+
+def _ref_greedy(lm, inputs_embeds, max_new, stop_ids=((835,), (2277, 29937)), eos=2):
+    """15-line manual loop over the reference's own forward(use_cache=True, past_key_values=tuple,
+    position_ids) -- HF generate() is unavailable for this class under transformers>=4.50."""
+    B, S0, _ = inputs_embeds.shape
+    past, ids, margins = None, [], []
+    x, total = dict(inputs_embeds=inputs_embeds), S0
+    for step in range(max_new):
+        pos = None if past is None else torch.full((B, 1), total - 1, dtype=torch.long)
+        out = lm(**x, attention_mask=torch.ones(B, total, dtype=torch.long), position_ids=pos, past_key_values=past,
+                 use_cache=True, return_dict=True)
+        past = out.past_key_values
+        logits = out.logits[:, -1].clone()
+        if step < 1:
+            logits[:, eos] = -float("inf")
+        t2 = logits.topk(2, -1).values
+        margins.append(t2[:, 0] - t2[:, 1])
+        nxt = logits.argmax(-1)
+        ids.append(nxt)
+        row0 = [int(t[0]) for t in ids]
+        if any(len(row0) >= len(s) and row0[-len(s):] == list(s) for s in stop_ids):
+            break
+        x = dict(input_ids=nxt[:, None])
+        total += 1
+    return torch.stack(ids, 1), torch.stack(margins, 1)
+
+
+def case_llama(M):
+    # tiny, 2 layers, ragged right padding
+    D, layers, heads, inter, V = 64, 2, 4, 172, 320
+    sd = gu.llama_weights(D, layers, inter, V, seed=401, std=0.2)
+    lm = ref_llama(M, D, layers, heads, inter, V)
+    load_sd(lm, sd, "llama_model.")
+    g = torch.Generator().manual_seed(10)
+    B, S = 3, 12
+    emb = (torch.randn(B, S, D, generator=g) * 0.5).requires_grad_(True)
+    mask = torch.ones(B, S, dtype=torch.long)
+    mask[1, -3:] = 0
+    mask[2, -1:] = 0
+    labels = torch.randint(3, V, (B, S), generator=g)
+    labels[:, :5] = -100
+    labels[mask == 0] = -100
+    out = lm(inputs_embeds=emb, attention_mask=mask, labels=labels, return_dict=True)
+    out.loss.backward()
+    with torch.no_grad():
+        gen_in = emb.detach()[:2, :7]
+        ids, margins = _ref_greedy(lm, gen_in, 12, stop_ids=((7,),))
+    save("llama_tiny", emb=emb.detach(), mask=mask, labels=labels, loss=out.loss, logits=out.logits,
+         demb=emb.grad, gen_ids=ids, gen_margins=margins, meta=np.array([D, layers, heads, inter, V, 401]))
+    # full width single layer (4096 / 11008 / 32 heads x 128), V=1000, S=24
+    D, layers, heads, inter, V = 4096, 1, 32, 11008, 1000
+    sd = gu.llama_weights(D, layers, inter, V, seed=402)
+    lm = ref_llama(M, D, layers, heads, inter, V)
+    load_sd(lm, sd, "llama_model.")
+    g = torch.Generator().manual_seed(11)
+    B, S = 2, 24
+    emb = (torch.randn(B, S, D, generator=g) * 0.02).requires_grad_(True)
+    mask = torch.ones(B, S, dtype=torch.long)
+    mask[1, -4:] = 0
+    labels = torch.randint(3, V, (B, S), generator=g)
+    labels[:, :10] = -100
+    labels[mask == 0] = -100
+    out = lm(inputs_embeds=emb, attention_mask=mask, labels=labels, return_dict=True)
+    out.loss.backward()
+    save("llama_fullwidth", seed=np.array([402, 11]), mask=mask, labels=labels, loss=out.loss,
+         logits_sub=out.logits[:, :, ::10], demb_sub=emb.grad[:, :, ::16],
+         meta=np.array([D, layers, heads, inter, V, 402]))
+
+
+def case_clamp_ce(M):
+    L = M["llama"].LlamaForCausalLM
+    g = torch.Generator().manual_seed(12)
+    res = {}
+    for name, scale in (("normal", 1.0), ("saturated", 8.0)):
+        x = (torch.randn(6, 100, generator=g) * scale).requires_grad_(True)
+        y = torch.randint(0, 100, (6,), generator=g)
+        y[2] = -100
+        if name == "saturated":
+            # force both clamp ends: one row's target prob < 1e-7, one row's target prob > 1-1e-7
+            with torch.no_grad():
+                x[0, y[0]] = x[0].min() - 30
+                x[1, y[1]] = x[1].max() + 40
+        loss = L.clamp_CE_loss(None, x, y)
+        loss.backward()
+        res[f"{name}_x"] = x.detach()
+        res[f"{name}_y"] = y
+        res[f"{name}_loss"] = loss
+        res[f"{name}_dx"] = x.grad
+    save("clamp_ce", **res)
+
+
+def case_composite(M):
+    """Glue of myriad.py:241-272,354-375,395-431 around the reference's importable modules,
+    full width / reduced depth (ViT 1 block, Q-Former 2 layers, LLaMA 1 layer, V=1000), B=2."""
+    N = M["networks"]
+    V = 1000
+    sd = {}
+    sd.update(gu.vit_weights(1408, 1, 16, int(1408 * 4.3637), 14, 257, seed=501))
+    sd.update(gu.qformer_weights(768, 2, 3072, 1408, seed=502))
+    sd.update(gu.llama_weights(4096, 1, 11008, V, seed=503))
+    sd.update(gu.adapter_weights(seed=504))
+    sd.update(gu.glue_weights(seed=505))
+    vit = ref_vit(M, 1408, 1, 16, 4.3637, 224)
+    load_sd(vit, sd, "visual_encoder.")
+    qf = ref_qformer(M, 768, 2, 12, 3072, 1408, 32)
+    load_sd(qf.bert, sd, "Qformer.bert.")
+    lm = ref_llama(M, 4096, 1, 32, 11008, V)
+    load_sd(lm, sd, "llama_model.")
+    for mod in (vit, qf, lm):
+        for p in mod.parameters():
+            p.requires_grad = False
+    ad = N.LoraAdaptorV2(dims=1408, input_dim=4)
+    load_sd(ad, sd, "expert_adaptor.")
+    ins = N.VEInstructorV2()
+    load_sd(ins, sd, "VEInstructor.")
+    tok = N.VETokenizer()
+    load_sd(tok, sd, "VETokenizer.")
+    lnv = nn.LayerNorm(1408)
+    lnv.load_state_dict({"weight": sd["ln_vision.weight"], "bias": sd["ln_vision.bias"]})
+    proj = nn.Linear(768, 4096)
+    proj.load_state_dict({"weight": sd["llama_proj.weight"], "bias": sd["llama_proj.bias"]})
+    for p in list(lnv.parameters()) + list(proj.parameters()):
+        p.requires_grad = False
+    qtok = sd["query_tokens"]
+    image, maps, before, after, tgt, tmask = gu.synthetic_batch(2, V, seed=506, pad_tail=1)
+    embed = lm.model.embed_tokens
+    res = dict(seed=np.array([501, 502, 503, 504, 505, 506]))
+    for arch, stage in (("mini_gpt4", 0), ("myriad", 0), ("myriad", 1), ("myriad", 2)):
+        for m in (ad, ins, tok):
+            m.zero_grad()
+        x = vit(image)
+        if arch == "myriad":
+            x = ad(x)
+        x = lnv(x.float())
+        q = qtok.expand(2, -1, -1)
+        if arch == "myriad" and stage in (1, 2):
+            q = torch.cat([q, ins(maps)], 1)
+        qo = qf.bert(query_embeds=q, encoder_hidden_states=x, encoder_attention_mask=torch.ones(2, 257, dtype=torch.long),
+                     return_dict=True).last_hidden_state
+        img = proj(qo)
+        if arch == "myriad" and stage in (0, 1):
+            img = torch.cat([img, tok(maps)], 1)
+        wrapped = torch.cat([embed(before), img, embed(after)], 1)
+        targets = tgt.masked_fill(tgt == 2, -100)
+        empty = torch.full((2, wrapped.shape[1] + 1), -100, dtype=torch.long)
+        labels = torch.cat([empty, targets], 1)
+        bos = embed(torch.ones(2, 1, dtype=torch.long))
+        emb = torch.cat([bos, wrapped, embed(tgt)], 1)
+        attn = torch.cat([torch.ones(2, 1 + wrapped.shape[1], dtype=torch.long), tmask], 1)
+        out = lm(inputs_embeds=emb, attention_mask=attn, labels=labels, return_dict=True)
+        key = f"{arch}_s{stage}"
+        res[key + "_loss"] = out.loss
+        res[key + "_S"] = np.array([emb.shape[1]])
+        if arch == "myriad":
+            out.loss.backward()
+            res[key + "_dA"] = ad.conv1.weight.grad.clone()
+            res[key + "_dB_sub"] = ad.conv2.weight.grad[::16].clone()
+            if stage in (1, 2):
+                res[key + "_instr_dw15_norm"] = ins.meta_net[15].weight.grad.norm()
+                res[key + "_instr_dw0"] = ins.meta_net[0].weight.grad.clone()
+            if stage in (0, 1):
+                res[key + "_tok_dw15_norm"] = tok.meta_net[15].weight.grad.norm()
+                res[key + "_tok_dw0"] = tok.meta_net[0].weight.grad.clone()
+                res[key + "_tok_dbase_sub"] = tok.base_prompts.grad[:, ::64].clone()
+    save("composite_fullwidth", **res)
+
+
+def case_optim(M):
+    O = M["optims"]
+
+    class FakeOpt:
+        def __init__(self):
+            self.param_groups = [{"lr": 0.0}]
+
+    opt = FakeOpt()
+    sch = O.LinearWarmupCosineLRScheduler(opt, max_epoch=10, iters_per_epoch=1600, min_lr=0.0, init_lr=1e-4,
+                                          warmup_steps=0, warmup_start_lr=1e-6)
+    pts = [(0, 0), (0, 1), (0, 799), (3, 100), (9, 1599)]
+    lrs = []
+    for e, s in pts:
+        sch.step(e, s)
+        lrs.append(opt.param_groups[0]["lr"])
+    sch2 = O.LinearWarmupCosineLRScheduler(opt, max_epoch=2, iters_per_epoch=100, min_lr=1e-5, init_lr=1e-3,
+                                           warmup_steps=20, warmup_start_lr=1e-6)
+    pts2 = [(0, 0), (0, 5), (0, 19), (0, 20), (1, 50)]
+    lrs2 = []
+    for e, s in pts2:
+        sch2.step(e, s)
+        lrs2.append(opt.param_groups[0]["lr"])
+    # AdamW as configured at runner_base.py:132-137 (third-party torch.optim.AdamW, pinned by this torch build)
+    g = torch.Generator().manual_seed(13)
+    p = torch.nn.Parameter(torch.randn(64, 32, generator=g))
+    b = torch.nn.Parameter(torch.randn(64, generator=g))
+    p0, b0 = p.detach().clone(), b.detach().clone()
+    ao = torch.optim.AdamW([{"params": [p], "weight_decay": 0.05}, {"params": [b], "weight_decay": 0}], lr=1e-4,
+                           weight_decay=0.05, betas=(0.9, 0.999))
+    grads = []
+    for k in range(3):
+        gp = torch.randn(64, 32, generator=g)
+        gb = torch.randn(64, generator=g)
+        p.grad, b.grad = gp.clone(), gb.clone()
+        for grp in ao.param_groups:
+            grp["lr"] = 1e-4 * (1 - 0.1 * k)
+        ao.step()
+        grads.append((gp, gb))
+    save("optim", pts=np.array(pts), lrs=np.array(lrs), pts2=np.array(pts2), lrs2=np.array(lrs2), p0=p0, b0=b0,
+         gp=torch.stack([x[0] for x in grads]), gb=torch.stack([x[1] for x in grads]), p3=p.detach(), b3=b.detach())
+
+
+CASES = dict(vit=case_vit, networks=case_networks, qformer=case_qformer, llama=case_llama, clamp_ce=case_clamp_ce,
+             composite=case_composite, optim=case_optim)
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--ref", default="/root/reference")
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    torch.set_num_threads(8)
+    M = load_reference(a.ref)
+    for name, fn in CASES.items():
+        if a.only and a.only != name:
+            continue
+        print("==", name)
+        fn(M)

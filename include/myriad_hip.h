@@ -1,0 +1,126 @@
+/* libmyriad_hip.so -- C ABI of the MI355X (gfx950) kernels behind the Myriad / MiniGPT-4 hot path.
+ *
+ * The reference (tzjtatata/Myriad) has no FFI of its own: every op below replaces a stock PyTorch op sequence
+ * inside the reference's nn.Module sub-blocks (file:line cited per entry, paths relative to the reference
+ * checkout).  The drop-in boundary one level up is the registered model class (myriad_amd.Myriad / MiniGPT4).
+ *
+ * Conventions: plain device pointers owned by the caller, explicit dims / leading
+ * dimensions in ELEMENTS, explicit hipStream_t, no hidden allocation (workspaces are passed in), re-entrant,
+ * no global state.  Every function returns 0 on success or a negative MH_ERR_* code and never throws.
+ * bf16 tensors are raw uint16 bit patterns; "f32" means IEEE float.
+ */
+#ifndef MYRIAD_HIP_H
+#define MYRIAD_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ihipStream_t* mh_stream_t; /* == hipStream_t */
+
+#define MH_OK 0
+#define MH_ERR_ARG (-1)
+#define MH_ERR_LAUNCH (-2)
+#define MH_ERR_UNSUPPORTED (-3)
+
+/* mh_gemm_bf16_nt flags */
+#define MH_GEMM_OUT_F32 1  /* C is f32 (else bf16) */
+#define MH_GEMM_GELU 2     /* erf-GELU after bias, before residual */
+#define MH_GEMM_REGSTAGE 4 /* register-staged LDS fill instead of LDS-DMA (A/B testing) */
+
+/* K1/K2  C[M,N] = alpha * A[M,K] . B[N,K]^T (+bias[N]) (GELU) (+residual[M,N] f32).  A,B bf16, K % 64 == 0.
+ * Replaces every nn.Linear on the path: eva_vit.py:124,146,55-59; Qformer.py:127-133,281,352,367;
+ * myriad.py:263 (llama_proj); modeling_llama.py:134-136,159-162,604; and their autograd dgrad/wgrad. */
+int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                    const float* bias, const float* residual, int ldr, int flags, float alpha, mh_stream_t s);
+
+/* K3/K4/K5 fused attention.  q/k/v/o token-major [B,S,ld] bf16, head h at columns [h*D,(h+1)*D); D in
+ * {<=64, <=96 (88), <=128}; lse [B,H,Sq] f32; bias optional additive [H,Sq,Sk] f32 (eva_vit.py:131-140);
+ * kv_len optional [B] valid-key counts (right padding, modeling_llama.py:43-54); causal aligns the last query
+ * with the last key (KV-cache decode: Sq=1).  Replaces eva_vit.py:125-145, Qformer.py:195-262,
+ * modeling_llama.py:197-222 and their autograd. */
+int mh_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* bias,
+                const int* kv_len, int B, int H, int Sq, int Sk, int D, long q_bs, int ldq, long k_bs, int ldk,
+                long v_bs, int ldv, long o_bs, int ldo, float scale, int causal, mh_stream_t s);
+int mh_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout, const float* lse,
+                float* delta_ws /* [B,H,Sq] f32 scratch */, void* dq, void* dk, void* dv, const float* bias,
+                const int* kv_len, int B, int H, int Sq, int Sk, int D, long q_bs, int ldq, long k_bs, int ldk,
+                long v_bs, int ldv, long o_bs, int ldo, long do_bs, int lddo, long dq_bs, int lddq, long dk_bs,
+                int lddk, long dv_bs, int lddv, float scale, int causal, mh_stream_t s);
+
+/* K7 RMSNorm (modeling_llama.py:66-74) f32 in -> bf16 out; bwd is dgrad-only (+ optional residual-grad add,
+ * optional bf16 copy of dx for the next dgrad GEMM). */
+int mh_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, int M, int D, float eps, mh_stream_t s);
+int mh_rmsnorm_bwd(const float* dy, const float* x, const float* w, const float* dres, float* dx, void* dx_bf16,
+                   int M, int D, float eps, mh_stream_t s);
+/* K6 LayerNorm (eva_vit.py:175-176; blip2.py:119-125; Qformer.py:106,288,374) f32 in -> bf16 and/or f32 out. */
+int mh_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, int M, int D,
+                     float eps, mh_stream_t s);
+int mh_layernorm_bwd(const float* dy, const float* x, const float* w, const float* dres, float* dx, void* dx_bf16,
+                     int M, int D, float eps, mh_stream_t s);
+
+/* K8 rotary, rotate-half form gathered by position id (modeling_llama.py:109-123); in place on heads
+ * [col0, col0 + n_heads*head_dim) of a [n_tok, ld] bf16 buffer; tables [max_pos, head_dim/2] f32; sign=-1 = bwd. */
+int mh_rope_inplace(void* x, int ld, int col0, int n_tok, int n_heads, int head_dim, const int* pos,
+                    const float* cos_tab, const float* sin_tab, float sign, mh_stream_t s);
+/* K9 SiLU-gated MLP elementwise (modeling_llama.py:139-140): gu = [M, 2I] = [gate | up] bf16. */
+int mh_silu_mul_fwd(const void* gu, void* h, int M, int I, mh_stream_t s);
+int mh_silu_mul_bwd(const void* dh, const void* gu, void* dgu, int M, int I, mh_stream_t s);
+/* erf-GELU on bf16 (Qformer.py:352-356 via ACT2FN["gelu"]) */
+int mh_gelu_fwd(const void* x, void* y, long n, mh_stream_t s);
+int mh_gelu_bwd(const void* dy, const void* x, void* dx, long n, mh_stream_t s);
+
+/* K10 rank-r adaptor y = x + (x A^T) B^T (networks.py:81-93), f32, r in {1,2,4,8}. */
+int mh_lowrank_fwd(const float* x, const float* A, const float* Bm, float* y, float* t, int M, int D, int R,
+                   mh_stream_t s);
+long mh_lowrank_bwd_ws_floats(int M, int D, int R);
+int mh_lowrank_bwd(const float* dy, const float* x, const float* t, const float* A, const float* Bm, float* dA,
+                   float* dB, float* dx, float* ws, int M, int D, int R, mh_stream_t s);
+
+/* K11 clamp-CE (modeling_llama.py:718-728) per-row loss + fused d(logits) (bf16, zero-padded to ldd). */
+int mh_clamp_ce(const float* logits, long ldl, const long* labels, float* row_loss, void* dlogits_bf16, long ldd,
+                int R, int V, float grad_scale, mh_stream_t s);
+int mh_sum_f32(const float* x, float* out, long n, float scale, mh_stream_t s);
+/* greedy step (evaluation_aqa_dataset.py:289-301 top_p=0.01 == arg-max; min_length ban of EOS) */
+int mh_argmax_rows(const float* logits, long ldl, long* out, float* margin, int R, int V, int ban_id, mh_stream_t s);
+
+/* K12 conv stacks of VEInstructorV2 / VETokenizer (networks.py:98-127,159-189) as im2col + mh_gemm_bf16_nt. */
+int mh_im2col_nhwc(const void* x, void* col, int B, int H, int W, int C, int kh, int kw, int pad, int Kpad,
+                   mh_stream_t s);
+int mh_col2im_nhwc(const void* dcol, float* dx, int B, int H, int W, int C, int kh, int kw, int pad, int Kpad,
+                   mh_stream_t s);
+int mh_relu_maxpool2_fwd(const void* y, long ldy, void* p, int B, int H, int W, int C, mh_stream_t s);
+int mh_relu_maxpool2_bwd(const float* dp, const void* y, long ldy, void* dy, long lddy, int B, int H, int W, int C,
+                         mh_stream_t s);
+int mh_conv_pack_weight(const float* W, const float* bias, void* Wp, int Cout, int K, int Kpad, mh_stream_t s);
+int mh_conv_unpack_grad(const float* dWp, float* dW, float* db, int Cout, int K, int Kpad, mh_stream_t s);
+
+/* K13 assembly of inputs_embeds (myriad.py:354-375,395-421) and generic data movement. */
+int mh_embed_gather(const void* table_bf16, const long* ids, const int* dst_rows, float* out, long n, int D, long ldo,
+                    mh_stream_t s);
+int mh_copy2d_f32(const float* src, long lds, float* dst, long ldd, long rows, int cols, int accumulate,
+                  mh_stream_t s);
+int mh_copy3d_f32(const float* src, long src_bstride, long lds, float* dst, long dst_bstride, long ldd, int nb,
+                  long rows, int cols, int accumulate, mh_stream_t s);
+int mh_gather_rows_f32_to_bf16(const float* src, long lds, const int* rows, void* dst, long n, int D, mh_stream_t s);
+int mh_scatter_rows_f32(const float* src, const int* rows, float* dst, long ldd, long n, int D, int accumulate,
+                        mh_stream_t s);
+int mh_cast_f32_to_bf16(const float* x, void* y, long n, mh_stream_t s);
+int mh_cast_bf16_to_f32(const void* x, float* y, long n, mh_stream_t s);
+int mh_transpose_to_bf16(const void* in, int in_is_f32, long ldi, void* out, long ldo, int R, int C, mh_stream_t s);
+int mh_colsum_f32(const float* in, long ld, float* out, long R, int C, mh_stream_t s);
+int mh_scale_f32(float* x, float a, long n, mh_stream_t s);
+
+/* K15 AdamW (runner_base.py:104-139) on a flat f32 buffer with optional bf16 shadow; step is 1-based. */
+int mh_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, float lr, float beta1,
+                  float beta2, float eps, float weight_decay, int step, float grad_scale, mh_stream_t s);
+
+/* library identity */
+const char* mh_version(void);
+int mh_target_arch(void); /* 950 */
+
+#ifdef __cplusplus
+}
+#endif
+#endif

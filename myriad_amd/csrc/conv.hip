@@ -1,0 +1,203 @@
+// K12: the vision-expert conv stacks (reference networks.py:98-127 VEInstructorV2, :159-189 VETokenizer)
+// as im2col + the MFMA GEMM.  Activations are NHWC bf16, so an im2col row is kh*kw contiguous C-chunks.
+// The bias rides along as one extra K column (im2col writes 1.0 there, the packed weight holds the bias),
+// so the forward GEMM needs no bias epilogue and the wgrad GEMM produces the bias gradient for free.
+// Master weights are fp32 in GEMM order [Cout, K], k = (ky*kw+kx)*Cin + ci; the checkpoint boundary
+// permutes to/from the reference's [Cout,Cin,kh,kw].  pack/unpack add/strip the bias column + K padding.
+#include "common.h"
+
+#define CV_NT 256
+static inline int cv_grid(long n) {
+  long g = (n + CV_NT - 1) / CV_NT;
+  if (g > 4096) g = 4096;
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+__global__ void im2col_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ col, int B, int H, int W, int C,
+                              int kh, int kw, int pad, int OH, int OW, int K, int Kpad) {
+  // one item = one (row m, 4-element group of the Kpad columns)
+  const int groups = Kpad >> 2;
+  const long total = (long)B * OH * OW * groups;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long m = it / groups;
+    const int k0 = (int)(it - m * groups) * 4;
+    const int ox = (int)(m % OW);
+    const int oy = (int)((m / OW) % OH);
+    const int b = (int)(m / ((long)OW * OH));
+    bf16_t v[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int k = k0 + e;
+      bf16_t val = 0;
+      if (k < K) {
+        const int tap = k / C, c = k - tap * C;
+        const int ky = tap / kw, kx = tap - ky * kw;
+        const int iy = oy + ky - pad, ix = ox + kx - pad;
+        if (iy >= 0 && iy < H && ix >= 0 && ix < W) val = x[(((long)b * H + iy) * W + ix) * C + c];
+      } else if (k == K) {
+        val = 0x3F80;  // 1.0 -> bias column
+      }
+      v[e] = val;
+    }
+    uint2 pk;
+    pk.x = (unsigned)v[0] | ((unsigned)v[1] << 16);
+    pk.y = (unsigned)v[2] | ((unsigned)v[3] << 16);
+    *reinterpret_cast<uint2*>(col + m * Kpad + k0) = pk;
+  }
+}
+
+extern "C" int mh_im2col_nhwc(const void* x, void* col, int B, int H, int W, int C, int kh, int kw, int pad, int Kpad,
+                              hipStream_t stream) {
+  const int OH = H + 2 * pad - kh + 1, OW = W + 2 * pad - kw + 1, K = kh * kw * C;
+  if (Kpad % 4 || Kpad < K + 1 || OH <= 0 || OW <= 0) return MH_ERR_ARG;
+  const long total = (long)B * OH * OW * (Kpad / 4);
+  hipLaunchKernelGGL(im2col_kernel, dim3(cv_grid(total)), dim3(CV_NT), 0, stream, (const bf16_t*)x, (bf16_t*)col, B, H,
+                     W, C, kh, kw, pad, OH, OW, K, Kpad);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// gather-form col2im: dx[b,y,x,c] = sum_taps dcol[(b, y+pad-ky, x+pad-kx)][tap*C + c]
+__global__ void col2im_kernel(const bf16_t* __restrict__ dcol, float* __restrict__ dx, int B, int H, int W, int C,
+                              int kh, int kw, int pad, int OH, int OW, int Kpad) {
+  const long total = (long)B * H * W * C;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(it % C);
+    const long p = it / C;
+    const int ix = (int)(p % W);
+    const int iy = (int)((p / W) % H);
+    const int b = (int)(p / ((long)W * H));
+    float s = 0.f;
+    for (int ky = 0; ky < kh; ++ky) {
+      const int oy = iy + pad - ky;
+      if (oy < 0 || oy >= OH) continue;
+      for (int kx = 0; kx < kw; ++kx) {
+        const int ox = ix + pad - kx;
+        if (ox < 0 || ox >= OW) continue;
+        s += bf2f(dcol[(((long)b * OH + oy) * OW + ox) * Kpad + (ky * kw + kx) * C + c]);
+      }
+    }
+    dx[it] = s;
+  }
+}
+
+extern "C" int mh_col2im_nhwc(const void* dcol, float* dx, int B, int H, int W, int C, int kh, int kw, int pad,
+                              int Kpad, hipStream_t stream) {
+  const int OH = H + 2 * pad - kh + 1, OW = W + 2 * pad - kw + 1;
+  if (OH <= 0 || OW <= 0) return MH_ERR_ARG;
+  hipLaunchKernelGGL(col2im_kernel, dim3(cv_grid((long)B * H * W * C)), dim3(CV_NT), 0, stream, (const bf16_t*)dcol,
+                     dx, B, H, W, C, kh, kw, pad, OH, OW, Kpad);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// ReLU -> MaxPool2d(2) on NHWC bf16 (reference networks.py:100-102 etc.).  ldy = row stride of y in
+// elements (the conv GEMM may write into a wider buffer).
+__global__ void relu_pool_fwd_kernel(const bf16_t* __restrict__ y, long ldy, bf16_t* __restrict__ p, int B, int H,
+                                     int W, int C) {
+  const int PH = H >> 1, PW = W >> 1;
+  const long total = (long)B * PH * PW * C;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(it % C);
+    const long q = it / C;
+    const int px = (int)(q % PW);
+    const int py = (int)((q / PW) % PH);
+    const int b = (int)(q / ((long)PW * PH));
+    const long base = ((long)b * H + 2 * py) * W + 2 * px;
+    float m = 0.f;  // relu floor
+    m = fmaxf(m, bf2f(y[base * ldy + c]));
+    m = fmaxf(m, bf2f(y[(base + 1) * ldy + c]));
+    m = fmaxf(m, bf2f(y[(base + W) * ldy + c]));
+    m = fmaxf(m, bf2f(y[(base + W + 1) * ldy + c]));
+    p[it] = f2bf(m);
+  }
+}
+
+// gradient goes to the first arg-max of the window (scan order) iff that max is > 0
+__global__ void relu_pool_bwd_kernel(const float* __restrict__ dp, const bf16_t* __restrict__ y, long ldy,
+                                     bf16_t* __restrict__ dy, long lddy, int B, int H, int W, int C) {
+  const int PH = H >> 1, PW = W >> 1;
+  const long total = (long)B * PH * PW * C;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const int c = (int)(it % C);
+    const long q = it / C;
+    const int px = (int)(q % PW);
+    const int py = (int)((q / PW) % PH);
+    const int b = (int)(q / ((long)PW * PH));
+    const long base = ((long)b * H + 2 * py) * W + 2 * px;
+    const long idx[4] = {base, base + 1, base + W, base + W + 1};
+    float best = bf2f(y[idx[0] * ldy + c]);
+    int arg = 0;
+#pragma unroll
+    for (int e = 1; e < 4; ++e) {
+      const float v = bf2f(y[idx[e] * ldy + c]);
+      if (v > best) { best = v; arg = e; }
+    }
+    const float g = best > 0.f ? dp[it] : 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) dy[idx[e] * lddy + c] = (e == arg) ? f2bf(g) : (bf16_t)0;
+  }
+}
+
+extern "C" int mh_relu_maxpool2_fwd(const void* y, long ldy, void* p, int B, int H, int W, int C,
+                                    hipStream_t stream) {
+  if ((H & 1) || (W & 1)) return MH_ERR_ARG;
+  hipLaunchKernelGGL(relu_pool_fwd_kernel, dim3(cv_grid((long)B * (H / 2) * (W / 2) * C)), dim3(CV_NT), 0, stream,
+                     (const bf16_t*)y, ldy, (bf16_t*)p, B, H, W, C);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+extern "C" int mh_relu_maxpool2_bwd(const float* dp, const void* y, long ldy, void* dy, long lddy, int B, int H, int W,
+                                    int C, hipStream_t stream) {
+  if ((H & 1) || (W & 1)) return MH_ERR_ARG;
+  hipLaunchKernelGGL(relu_pool_bwd_kernel, dim3(cv_grid((long)B * (H / 2) * (W / 2) * C)), dim3(CV_NT), 0, stream, dp,
+                     (const bf16_t*)y, ldy, (bf16_t*)dy, lddy, B, H, W, C);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// Master conv weights are held in GEMM order  W[co][(ky*kw+kx)*Cin + ci]  (fp32; the checkpoint
+// boundary permutes to/from the reference's [Cout,Cin,kh,kw] -- myriad_amd/networks.py).
+// pack: Wp[co][k] = bf16(W[co][k]) k<K ; Wp[co][K] = bias[co] ; rest 0
+__global__ void conv_pack_kernel(const float* __restrict__ Wt, const float* __restrict__ bias, bf16_t* __restrict__ Wp,
+                                 int Cout, int K, int Kpad) {
+  const long total = (long)Cout * Kpad;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(it / Kpad), k = (int)(it - (long)co * Kpad);
+    float v = 0.f;
+    if (k < K) v = Wt[(long)co * K + k];
+    else if (k == K) v = bias ? bias[co] : 0.f;
+    Wp[it] = f2bf(v);
+  }
+}
+// unpack gradients: dW[co][k] = dWp[co][k], db[co] = dWp[co][K]
+__global__ void conv_unpack_kernel(const float* __restrict__ dWp, float* __restrict__ dW, float* __restrict__ db,
+                                   int Cout, int K, int Kpad) {
+  const long total = (long)Cout * (K + 1);
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const int co = (int)(it / (K + 1)), j = (int)(it - (long)co * (K + 1));
+    if (j == K) {
+      if (db) db[co] = dWp[(long)co * Kpad + K];
+    } else {
+      dW[(long)co * K + j] = dWp[(long)co * Kpad + j];
+    }
+  }
+}
+
+extern "C" int mh_conv_pack_weight(const float* W, const float* bias, void* Wp, int Cout, int K, int Kpad,
+                                   hipStream_t stream) {
+  if (Kpad < K + 1) return MH_ERR_ARG;
+  hipLaunchKernelGGL(conv_pack_kernel, dim3(cv_grid((long)Cout * Kpad)), dim3(CV_NT), 0, stream, W, bias,
+                     (bf16_t*)Wp, Cout, K, Kpad);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+extern "C" int mh_conv_unpack_grad(const float* dWp, float* dW, float* db, int Cout, int K, int Kpad,
+                                   hipStream_t stream) {
+  if (Kpad < K + 1) return MH_ERR_ARG;
+  hipLaunchKernelGGL(conv_unpack_kernel, dim3(cv_grid((long)Cout * (K + 1))), dim3(CV_NT), 0, stream, dWp, dW, db,
+                     Cout, K, Kpad);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}

@@ -1,0 +1,383 @@
+// HBM-bound elementwise / data-movement kernels (K8 rotary, K9 SiLU-gate, GELU, casts, transposes,
+// embedding gather K13, strided copies).  All vectorised to 8-16 B per lane (wave64, coalesced).
+#include "common.h"
+
+#define EW_NT 256
+static inline int ew_grid(long n_items) {
+  long g = (n_items + EW_NT - 1) / EW_NT;
+  if (g > 256L * 16) g = 256L * 16;  // grid-stride beyond 16 blocks/CU
+  if (g < 1) g = 1;
+  return (int)g;
+}
+
+// ---- K8 rotary (rotate-half form, gathered by position id) -----------------------------------
+// reference modeling_llama.py:109-123.  x: [n_tok, ld] bf16, heads [nh] of width d starting at col0.
+// cos/sin tables [max_pos, d/2] fp32.  sign=+1 forward, -1 backward (transpose of the rotation).
+__global__ void rope_kernel(bf16_t* x, int ld, int col0, long n_tok, int nh, int d, const int* __restrict__ pos,
+                            const float* __restrict__ cs, const float* __restrict__ sn, float sign) {
+  const int half = d >> 1;
+  const int per_tok = nh * (half >> 2);  // items of 4 pairs
+  const long total = n_tok * per_tok;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long tok = it / per_tok;
+    const int rem = (int)(it - tok * per_tok);
+    const int h = rem / (half >> 2), i = (rem % (half >> 2)) * 4;
+    bf16_t* p = x + tok * ld + col0 + h * d + i;
+    const int ps = pos[tok];
+    const float4_t c = *reinterpret_cast<const float4_t*>(cs + (size_t)ps * half + i);
+    const float4_t s = *reinterpret_cast<const float4_t*>(sn + (size_t)ps * half + i);
+    const short4_t a = *reinterpret_cast<const short4_t*>(p);
+    const short4_t b = *reinterpret_cast<const short4_t*>(p + half);
+    short4_t oa, ob;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x1 = bf2f((bf16_t)a[e]), x2 = bf2f((bf16_t)b[e]);
+      oa[e] = (short)f2bf(x1 * c[e] - sign * x2 * s[e]);
+      ob[e] = (short)f2bf(x2 * c[e] + sign * x1 * s[e]);
+    }
+    *reinterpret_cast<short4_t*>(p) = oa;
+    *reinterpret_cast<short4_t*>(p + half) = ob;
+  }
+}
+
+extern "C" int mh_rope_inplace(void* x, int ld, int col0, int n_tok, int n_heads, int head_dim, const int* pos,
+                               const float* cos_tab, const float* sin_tab, float sign, hipStream_t stream) {
+  if (n_tok <= 0) return MH_OK;
+  if (head_dim % 8 || ld % 4 || col0 % 4) return MH_ERR_ARG;
+  const long items = (long)n_tok * n_heads * (head_dim / 8);
+  hipLaunchKernelGGL(rope_kernel, dim3(ew_grid(items)), dim3(EW_NT), 0, stream, (bf16_t*)x, ld, col0, (long)n_tok,
+                     n_heads, head_dim, pos, cos_tab, sin_tab, sign);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// ---- K9 SiLU-gated MLP: h = silu(g) * u, gu = [M, 2I] = [gate | up] ---------------------------
+// reference modeling_llama.py:139-140
+__global__ void silu_mul_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ h, long M, int I) {
+  const int per_row = I >> 3;
+  const long total = M * per_row;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long m = it / per_row;
+    const int c = (int)(it - m * per_row) * 8;
+    const short8_t g = *reinterpret_cast<const short8_t*>(gu + m * 2 * I + c);
+    const short8_t u = *reinterpret_cast<const short8_t*>(gu + m * 2 * I + I + c);
+    short8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float gv = bf2f((bf16_t)g[e]), uv = bf2f((bf16_t)u[e]);
+      o[e] = (short)f2bf(gv / (1.f + __expf(-gv)) * uv);
+    }
+    *reinterpret_cast<short8_t*>(h + m * I + c) = o;
+  }
+}
+
+__global__ void silu_mul_bwd_kernel(const bf16_t* __restrict__ dh, const bf16_t* __restrict__ gu,
+                                    bf16_t* __restrict__ dgu, long M, int I) {
+  const int per_row = I >> 3;
+  const long total = M * per_row;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long m = it / per_row;
+    const int c = (int)(it - m * per_row) * 8;
+    const short8_t g = *reinterpret_cast<const short8_t*>(gu + m * 2 * I + c);
+    const short8_t u = *reinterpret_cast<const short8_t*>(gu + m * 2 * I + I + c);
+    const short8_t d = *reinterpret_cast<const short8_t*>(dh + m * I + c);
+    short8_t og, ou;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float gv = bf2f((bf16_t)g[e]), uv = bf2f((bf16_t)u[e]), dv = bf2f((bf16_t)d[e]);
+      const float sg = 1.f / (1.f + __expf(-gv));
+      const float silu = gv * sg;
+      og[e] = (short)f2bf(dv * uv * (sg + silu * (1.f - sg)));
+      ou[e] = (short)f2bf(dv * silu);
+    }
+    *reinterpret_cast<short8_t*>(dgu + m * 2 * I + c) = og;
+    *reinterpret_cast<short8_t*>(dgu + m * 2 * I + I + c) = ou;
+  }
+}
+
+extern "C" int mh_silu_mul_fwd(const void* gu, void* h, int M, int I, hipStream_t stream) {
+  if (M <= 0) return MH_OK;
+  if (I % 8) return MH_ERR_ARG;
+  hipLaunchKernelGGL(silu_mul_fwd_kernel, dim3(ew_grid((long)M * (I / 8))), dim3(EW_NT), 0, stream,
+                     (const bf16_t*)gu, (bf16_t*)h, (long)M, I);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+extern "C" int mh_silu_mul_bwd(const void* dh, const void* gu, void* dgu, int M, int I, hipStream_t stream) {
+  if (M <= 0) return MH_OK;
+  if (I % 8) return MH_ERR_ARG;
+  hipLaunchKernelGGL(silu_mul_bwd_kernel, dim3(ew_grid((long)M * (I / 8))), dim3(EW_NT), 0, stream,
+                     (const bf16_t*)dh, (const bf16_t*)gu, (bf16_t*)dgu, (long)M, I);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// ---- GELU (erf form) on bf16, fwd and bwd ----------------------------------------------------
+__global__ void gelu_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, long n8) {
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < n8; it += (long)gridDim.x * blockDim.x) {
+    const short8_t v = *reinterpret_cast<const short8_t*>(x + it * 8);
+    short8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(gelu_erf(bf2f((bf16_t)v[e])));
+    *reinterpret_cast<short8_t*>(y + it * 8) = o;
+  }
+}
+__global__ void gelu_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x, bf16_t* __restrict__ dx,
+                                long n8) {
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < n8; it += (long)gridDim.x * blockDim.x) {
+    const short8_t v = *reinterpret_cast<const short8_t*>(x + it * 8);
+    const short8_t g = *reinterpret_cast<const short8_t*>(dy + it * 8);
+    short8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (short)f2bf(bf2f((bf16_t)g[e]) * gelu_erf_grad(bf2f((bf16_t)v[e])));
+    *reinterpret_cast<short8_t*>(dx + it * 8) = o;
+  }
+}
+extern "C" int mh_gelu_fwd(const void* x, void* y, long n, hipStream_t stream) {
+  if (n <= 0) return MH_OK;
+  if (n % 8) return MH_ERR_ARG;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(ew_grid(n / 8)), dim3(EW_NT), 0, stream, (const bf16_t*)x, (bf16_t*)y,
+                     n / 8);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+extern "C" int mh_gelu_bwd(const void* dy, const void* x, void* dx, long n, hipStream_t stream) {
+  if (n <= 0) return MH_OK;
+  if (n % 8) return MH_ERR_ARG;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(ew_grid(n / 8)), dim3(EW_NT), 0, stream, (const bf16_t*)dy,
+                     (const bf16_t*)x, (bf16_t*)dx, n / 8);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// ---- casts -----------------------------------------------------------------------------------
+__global__ void cast_f32_bf16_kernel(const float* __restrict__ x, bf16_t* __restrict__ y, long n4) {
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < n4; it += (long)gridDim.x * blockDim.x) {
+    const float4_t v = *reinterpret_cast<const float4_t*>(x + it * 4);
+    uint2 pk;
+    pk.x = pack_bf2(v[0], v[1]);
+    pk.y = pack_bf2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(y + it * 4) = pk;
+  }
+}
+__global__ void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, float* __restrict__ y, long n4) {
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < n4; it += (long)gridDim.x * blockDim.x) {
+    const short4_t v = *reinterpret_cast<const short4_t*>(x + it * 4);
+    *reinterpret_cast<float4_t*>(y + it * 4) =
+        (float4_t){bf2f((bf16_t)v[0]), bf2f((bf16_t)v[1]), bf2f((bf16_t)v[2]), bf2f((bf16_t)v[3])};
+  }
+}
+extern "C" int mh_cast_f32_to_bf16(const float* x, void* y, long n, hipStream_t stream) {
+  if (n <= 0) return MH_OK;
+  if (n % 4) return MH_ERR_ARG;
+  hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3(ew_grid(n / 4)), dim3(EW_NT), 0, stream, x, (bf16_t*)y, n / 4);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+extern "C" int mh_cast_bf16_to_f32(const void* x, float* y, long n, hipStream_t stream) {
+  if (n <= 0) return MH_OK;
+  if (n % 4) return MH_ERR_ARG;
+  hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3(ew_grid(n / 4)), dim3(EW_NT), 0, stream, (const bf16_t*)x, y, n / 4);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// ---- 2-D strided copies (concat / slice assembly, K13) ---------------------------------------
+// dst[r*ldd + c] (=|+=) src[r*lds + c], fp32, cols % 4 == 0
+__global__ void copy2d_f32_kernel(const float* __restrict__ src, long lds, float* dst, long ldd, long rows, int cols4,
+                                  int accumulate) {
+  const long total = rows * cols4;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long r = it / cols4;
+    const int c = (int)(it - r * cols4) * 4;
+    float4_t v = *reinterpret_cast<const float4_t*>(src + r * lds + c);
+    if (accumulate) {
+      const float4_t d = *reinterpret_cast<const float4_t*>(dst + r * ldd + c);
+      v[0] += d[0]; v[1] += d[1]; v[2] += d[2]; v[3] += d[3];
+    }
+    *reinterpret_cast<float4_t*>(dst + r * ldd + c) = v;
+  }
+}
+extern "C" int mh_copy2d_f32(const float* src, long lds, float* dst, long ldd, long rows, int cols, int accumulate,
+                             hipStream_t stream) {
+  if (rows <= 0 || cols <= 0) return MH_OK;
+  if (cols % 4 || lds % 4 || ldd % 4) return MH_ERR_ARG;
+  hipLaunchKernelGGL(copy2d_f32_kernel, dim3(ew_grid(rows * (cols / 4))), dim3(EW_NT), 0, stream, src, lds, dst, ldd,
+                     rows, cols / 4, accumulate);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// batched variant: dst[b][r][c] = src[b][r][c] with batch strides (elements)
+__global__ void copy3d_f32_kernel(const float* __restrict__ src, long sb, long lds, float* dst, long db, long ldd,
+                                  int nb, long rows, int cols4, int accumulate) {
+  const long per_b = rows * cols4;
+  const long total = per_b * nb;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long b = it / per_b;
+    const long rem = it - b * per_b;
+    const long r = rem / cols4;
+    const int c = (int)(rem - r * cols4) * 4;
+    float4_t v = *reinterpret_cast<const float4_t*>(src + b * sb + r * lds + c);
+    float* d = dst + b * db + r * ldd + c;
+    if (accumulate) {
+      const float4_t o = *reinterpret_cast<const float4_t*>(d);
+      v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+    }
+    *reinterpret_cast<float4_t*>(d) = v;
+  }
+}
+extern "C" int mh_copy3d_f32(const float* src, long src_bstride, long lds, float* dst, long dst_bstride, long ldd,
+                             int nb, long rows, int cols, int accumulate, hipStream_t stream) {
+  if (rows <= 0 || cols <= 0 || nb <= 0) return MH_OK;
+  if (cols % 4 || lds % 4 || ldd % 4 || src_bstride % 4 || dst_bstride % 4) return MH_ERR_ARG;
+  hipLaunchKernelGGL(copy3d_f32_kernel, dim3(ew_grid(nb * rows * (cols / 4))), dim3(EW_NT), 0, stream, src,
+                     src_bstride, lds, dst, dst_bstride, ldd, nb, rows, cols / 4, accumulate);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// ---- K13 embedding gather: out[dst_row[i]] = table[ids[i]] (bf16 table -> fp32 residual stream)
+__global__ void embed_gather_kernel(const bf16_t* __restrict__ table, const long* __restrict__ ids,
+                                    const int* __restrict__ dst_rows, float* out, long n, int D, long ldo) {
+  const int per_row = D >> 3;
+  const long total = n * per_row;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long i = it / per_row;
+    const int c = (int)(it - i * per_row) * 8;
+    const short8_t v = *reinterpret_cast<const short8_t*>(table + ids[i] * D + c);
+    float* o = out + (long)(dst_rows ? dst_rows[i] : i) * ldo + c;
+    *reinterpret_cast<float4_t*>(o) =
+        (float4_t){bf2f((bf16_t)v[0]), bf2f((bf16_t)v[1]), bf2f((bf16_t)v[2]), bf2f((bf16_t)v[3])};
+    *reinterpret_cast<float4_t*>(o + 4) =
+        (float4_t){bf2f((bf16_t)v[4]), bf2f((bf16_t)v[5]), bf2f((bf16_t)v[6]), bf2f((bf16_t)v[7])};
+  }
+}
+extern "C" int mh_embed_gather(const void* table_bf16, const long* ids, const int* dst_rows, float* out, long n, int D,
+                               long ldo, hipStream_t stream) {
+  if (n <= 0) return MH_OK;
+  if (D % 8 || ldo % 4) return MH_ERR_ARG;
+  hipLaunchKernelGGL(embed_gather_kernel, dim3(ew_grid(n * (D / 8))), dim3(EW_NT), 0, stream,
+                     (const bf16_t*)table_bf16, ids, dst_rows, out, n, D, ldo);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// gather rows of an fp32 matrix (used to pick the label-bearing rows before lm_head) -> bf16
+__global__ void gather_rows_f32_bf16_kernel(const float* __restrict__ src, long lds, const int* __restrict__ rows,
+                                            bf16_t* __restrict__ dst, long n, int D) {
+  const int per_row = D >> 2;
+  const long total = n * per_row;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long i = it / per_row;
+    const int c = (int)(it - i * per_row) * 4;
+    const float4_t v = *reinterpret_cast<const float4_t*>(src + (long)rows[i] * lds + c);
+    uint2 pk;
+    pk.x = pack_bf2(v[0], v[1]);
+    pk.y = pack_bf2(v[2], v[3]);
+    *reinterpret_cast<uint2*>(dst + i * D + c) = pk;
+  }
+}
+// scatter-add rows back: dst[rows[i]] += src[i]  (fp32); rows must be unique
+__global__ void scatter_rows_f32_kernel(const float* __restrict__ src, const int* __restrict__ rows, float* dst,
+                                        long ldd, long n, int D, int accumulate) {
+  const int per_row = D >> 2;
+  const long total = n * per_row;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long i = it / per_row;
+    const int c = (int)(it - i * per_row) * 4;
+    float4_t v = *reinterpret_cast<const float4_t*>(src + i * D + c);
+    float* d = dst + (long)rows[i] * ldd + c;
+    if (accumulate) {
+      const float4_t o = *reinterpret_cast<const float4_t*>(d);
+      v[0] += o[0]; v[1] += o[1]; v[2] += o[2]; v[3] += o[3];
+    }
+    *reinterpret_cast<float4_t*>(d) = v;
+  }
+}
+extern "C" int mh_gather_rows_f32_to_bf16(const float* src, long lds, const int* rows, void* dst, long n, int D,
+                                          hipStream_t stream) {
+  if (n <= 0) return MH_OK;
+  if (D % 4 || lds % 4) return MH_ERR_ARG;
+  hipLaunchKernelGGL(gather_rows_f32_bf16_kernel, dim3(ew_grid(n * (D / 4))), dim3(EW_NT), 0, stream, src, lds, rows,
+                     (bf16_t*)dst, n, D);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+extern "C" int mh_scatter_rows_f32(const float* src, const int* rows, float* dst, long ldd, long n, int D,
+                                   int accumulate, hipStream_t stream) {
+  if (n <= 0) return MH_OK;
+  if (D % 4 || ldd % 4) return MH_ERR_ARG;
+  hipLaunchKernelGGL(scatter_rows_f32_kernel, dim3(ew_grid(n * (D / 4))), dim3(EW_NT), 0, stream, src, rows, dst, ldd,
+                     n, D, accumulate);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// ---- transpose to bf16 with zero padding: out[c][r] = in[r][c], out is [C, ldo], r >= R -> 0 ----
+// 64x64 tiles through LDS (+1 pad), coalesced on both sides.  IN_F32 selects fp32 or bf16 input.
+template <bool IN_F32>
+__global__ __launch_bounds__(256) void transpose_kernel(const void* __restrict__ in_, long ldi, bf16_t* __restrict__ out,
+                                                        long ldo, int R, int C) {
+  __shared__ float tile[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    float v = 0.f;
+    if (r < R && c < C) {
+      if (IN_F32) v = reinterpret_cast<const float*>(in_)[(long)r * ldi + c];
+      else v = bf2f(reinterpret_cast<const bf16_t*>(in_)[(long)r * ldi + c]);
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < C && r < ldo) out[(long)c * ldo + r] = f2bf(tile[tx][i]);
+  }
+}
+extern "C" int mh_transpose_to_bf16(const void* in, int in_is_f32, long ldi, void* out, long ldo, int R, int C,
+                                    hipStream_t stream) {
+  if (R <= 0 || C <= 0) return MH_OK;
+  if (ldo < R) return MH_ERR_ARG;
+  // cover [0, ldo) along R so the padding columns are zero-filled
+  const dim3 grid((C + 63) / 64, (int)((ldo + 63) / 64));
+  if (in_is_f32)
+    hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, stream, in, ldi, (bf16_t*)out, ldo, R, C);
+  else
+    hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, stream, in, ldi, (bf16_t*)out, ldo, R, C);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// ---- column sums (bias gradients): out[c] = sum_r in[r][c], fp32 in -----------------------------
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ in, long ld, float* __restrict__ out,
+                                                     long R, int C) {
+  __shared__ float part[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int ty = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < C)
+    for (long r = ty; r < R; r += 4) s += in[r * ld + c];
+  part[ty][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (ty == 0 && c < C) out[c] = part[0][threadIdx.x] + part[1][threadIdx.x] + part[2][threadIdx.x] + part[3][threadIdx.x];
+}
+extern "C" int mh_colsum_f32(const float* in, long ld, float* out, long R, int C, hipStream_t stream) {
+  if (C <= 0) return MH_OK;
+  hipLaunchKernelGGL(colsum_kernel, dim3((C + 63) / 64), dim3(256), 0, stream, in, ld, out, R, C);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// ---- scale / axpy on fp32 ----------------------------------------------------------------------
+__global__ void scale_f32_kernel(float* x, float a, long n) {
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) x[i] *= a;
+}
+extern "C" int mh_scale_f32(float* x, float a, long n, hipStream_t stream) {
+  if (n <= 0) return MH_OK;
+  hipLaunchKernelGGL(scale_f32_kernel, dim3(ew_grid(n)), dim3(EW_NT), 0, stream, x, a, n);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}

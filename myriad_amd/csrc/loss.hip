@@ -1,0 +1,110 @@
+// K11: clamp-CE loss (reference modeling_llama.py:718-728): softmax -> clamp(p, 1e-7, 1-1e-7) -> log -> NLL,
+// mean over labels != -100, with the analytically fused backward:
+//     dL/dx_j = g * (p_j - [j==t])   if 1e-7 <= p_t <= 1-1e-7   else 0      (clamp kills the whole row's grad)
+// fp32 logits in, bf16 d(logits) out (A operand of the lm_head dgrad GEMM).  One 256-thread workgroup per row;
+// HBM-bound: 4*V bytes read twice + 2*V written per row.
+// Also: deterministic fp32 sum (loss reduction) and row arg-max (greedy decode, K5 decode path).
+#include "common.h"
+
+#define LNT 256
+#define LNW 4
+
+__global__ __launch_bounds__(LNT) void clamp_ce_kernel(const float* __restrict__ logits, long ldl,
+                                                       const long* __restrict__ labels, float* __restrict__ row_loss,
+                                                       bf16_t* __restrict__ dlogits, long ldd, int V, float gscale) {
+  __shared__ float red[LNW];
+  const long row = blockIdx.x;
+  const float* x = logits + row * ldl;
+  const long t = labels[row];
+  float mx = -__builtin_inff();
+  for (int j = threadIdx.x; j < V; j += LNT) mx = fmaxf(mx, x[j]);
+  mx = block_max<LNW>(mx, red);
+  float se = 0.f;
+  for (int j = threadIdx.x; j < V; j += LNT) se += expf(x[j] - mx);
+  se = block_sum<LNW>(se, red);
+  const float inv = 1.f / se;
+  float gate = 0.f;
+  if (t >= 0 && t < V) {
+    const float pt = expf(x[t] - mx) * inv;
+    const float pc = fminf(fmaxf(pt, 1e-7f), 1.f - 1e-7f);
+    if (threadIdx.x == 0) row_loss[row] = -logf(pc);
+    gate = (pt >= 1e-7f && pt <= 1.f - 1e-7f) ? gscale : 0.f;
+  } else if (threadIdx.x == 0) {
+    row_loss[row] = 0.f;
+  }
+  if (dlogits) {
+    bf16_t* d = dlogits + row * ldd;
+    for (int j = threadIdx.x; j < ldd; j += LNT) {
+      float g = 0.f;
+      if (j < V && gate != 0.f) g = gate * (expf(x[j] - mx) * inv - (j == t ? 1.f : 0.f));
+      d[j] = f2bf(g);
+    }
+  }
+}
+
+extern "C" int mh_clamp_ce(const float* logits, long ldl, const long* labels, float* row_loss, void* dlogits_bf16,
+                           long ldd, int R, int V, float grad_scale, hipStream_t stream) {
+  if (R <= 0) return MH_OK;
+  if (dlogits_bf16 && ldd < V) return MH_ERR_ARG;
+  hipLaunchKernelGGL(clamp_ce_kernel, dim3(R), dim3(LNT), 0, stream, logits, ldl, labels, row_loss,
+                     (bf16_t*)dlogits_bf16, ldd, V, grad_scale);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// out[0] = scale * sum_i x[i]   (single workgroup, fixed summation order -> deterministic)
+__global__ __launch_bounds__(LNT) void sum_kernel(const float* __restrict__ x, float* __restrict__ out, long n, float scale) {
+  __shared__ float red[LNW];
+  float s = 0.f;
+  for (long i = threadIdx.x; i < n; i += LNT) s += x[i];
+  s = block_sum<LNW>(s, red);
+  if (threadIdx.x == 0) out[0] = s * scale;
+}
+extern "C" int mh_sum_f32(const float* x, float* out, long n, float scale, hipStream_t stream) {
+  hipLaunchKernelGGL(sum_kernel, dim3(1), dim3(LNT), 0, stream, x, out, n, scale);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// row arg-max (first index on ties, like torch.argmax) with optional banned id (min_length / EOS ban) and
+// optional top1-top2 margin output.
+__global__ __launch_bounds__(LNT) void argmax_kernel(const float* __restrict__ logits, long ldl, long* __restrict__ out,
+                                                     float* __restrict__ margin, int V, int ban_id) {
+  __shared__ float sv[LNT];
+  __shared__ int si[LNT];
+  __shared__ float s2[LNT];
+  const long row = blockIdx.x;
+  const float* x = logits + row * ldl;
+  float best = -__builtin_inff(), second = -__builtin_inff();
+  int bi = 0x7fffffff;
+  for (int j = threadIdx.x; j < V; j += LNT) {
+    const float v = (j == ban_id) ? -__builtin_inff() : x[j];
+    if (v > best) { second = best; best = v; bi = j; }
+    else if (v > second) second = v;
+  }
+  sv[threadIdx.x] = best; si[threadIdx.x] = bi; s2[threadIdx.x] = second;
+  __syncthreads();
+  for (int o = LNT / 2; o > 0; o >>= 1) {
+    if (threadIdx.x < o) {
+      const float a = sv[threadIdx.x], b = sv[threadIdx.x + o];
+      const int ia = si[threadIdx.x], ib = si[threadIdx.x + o];
+      const float a2 = s2[threadIdx.x], b2 = s2[threadIdx.x + o];
+      const bool take_b = (b > a) || (b == a && ib < ia);
+      sv[threadIdx.x] = take_b ? b : a;
+      si[threadIdx.x] = take_b ? ib : ia;
+      s2[threadIdx.x] = fmaxf(fmaxf(a2, b2), take_b ? a : b);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[row] = si[0];
+    if (margin) margin[row] = sv[0] - s2[0];
+  }
+}
+extern "C" int mh_argmax_rows(const float* logits, long ldl, long* out, float* margin, int R, int V, int ban_id,
+                              hipStream_t stream) {
+  if (R <= 0) return MH_OK;
+  hipLaunchKernelGGL(argmax_kernel, dim3(R), dim3(LNT), 0, stream, logits, ldl, out, margin, V, ban_id);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}

@@ -1,0 +1,209 @@
+// K6/K7: fused LayerNorm / RMSNorm, fwd and dgrad-only bwd (all norm weights on the hot path are frozen).
+// Residual streams are fp32 in HBM; the normalised output feeding an MFMA GEMM is written as bf16.
+// One 256-thread workgroup per row, float4 loads (HBM-bound: algorithmic bytes = 4*D in + 2*D out per row).
+//   RMSNorm  : reference modeling_llama.py:66-74   (fp32 variance, eps inside rsqrt)
+//   LayerNorm: reference eva_vit.py:175-176 (eps 1e-6), blip2.py:119-125 (ln_vision fp32, eps 1e-5),
+//              Qformer.py:106,288,374 (eps 1e-12)
+#include "common.h"
+
+#define NT 256
+#define NW 4
+
+// ---- RMSNorm ---------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         bf16_t* __restrict__ y, int D, float eps) {
+  __shared__ float red[NW];
+  const size_t row = blockIdx.x;
+  const float* xr = x + row * D;
+  float ss = 0.f;
+  for (int i = threadIdx.x * 4; i < D; i += NT * 4) {
+    const float4_t v = *reinterpret_cast<const float4_t*>(xr + i);
+    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  ss = block_sum<NW>(ss, red);
+  const float r = rsqrtf(ss / D + eps);
+  for (int i = threadIdx.x * 4; i < D; i += NT * 4) {
+    const float4_t v = *reinterpret_cast<const float4_t*>(xr + i);
+    const float4_t g = *reinterpret_cast<const float4_t*>(w + i);
+    uint2 pk;
+    pk.x = pack_bf2(g[0] * (v[0] * r), g[1] * (v[1] * r));
+    pk.y = pack_bf2(g[2] * (v[2] * r), g[3] * (v[3] * r));
+    *reinterpret_cast<uint2*>(y + row * D + i) = pk;
+  }
+}
+
+// dx = r*(w*dy) - x * r^3 * mean(x * w*dy)  (+ dres) ; optional bf16 copy for the next dgrad GEMM
+__global__ __launch_bounds__(NT) void rmsnorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                         const float* __restrict__ w, const float* dres, float* dx,
+                                                         bf16_t* dx_bf, int D, float eps) {
+  __shared__ float red[NW];
+  const size_t row = blockIdx.x;
+  const float* xr = x + row * D;
+  const float* gr = dy + row * D;
+  float ss = 0.f, dot = 0.f;
+  for (int i = threadIdx.x * 4; i < D; i += NT * 4) {
+    const float4_t v = *reinterpret_cast<const float4_t*>(xr + i);
+    const float4_t g = *reinterpret_cast<const float4_t*>(gr + i);
+    const float4_t ww = *reinterpret_cast<const float4_t*>(w + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      ss += v[e] * v[e];
+      dot += v[e] * ww[e] * g[e];
+    }
+  }
+  ss = block_sum<NW>(ss, red);
+  dot = block_sum<NW>(dot, red);
+  const float r = rsqrtf(ss / D + eps);
+  const float c = r * r * r * dot / D;
+  for (int i = threadIdx.x * 4; i < D; i += NT * 4) {
+    const float4_t v = *reinterpret_cast<const float4_t*>(xr + i);
+    const float4_t g = *reinterpret_cast<const float4_t*>(gr + i);
+    const float4_t ww = *reinterpret_cast<const float4_t*>(w + i);
+    float4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = r * ww[e] * g[e] - v[e] * c;
+    if (dres) {
+      const float4_t d = *reinterpret_cast<const float4_t*>(dres + row * D + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += d[e];
+    }
+    if (dx) *reinterpret_cast<float4_t*>(dx + row * D + i) = o;
+    if (dx_bf) {
+      uint2 pk;
+      pk.x = pack_bf2(o[0], o[1]);
+      pk.y = pack_bf2(o[2], o[3]);
+      *reinterpret_cast<uint2*>(dx_bf + row * D + i) = pk;
+    }
+  }
+}
+
+// ---- LayerNorm -------------------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void layernorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ b, bf16_t* y_bf, float* y_f32,
+                                                           int D, float eps) {
+  __shared__ float red[NW];
+  const size_t row = blockIdx.x;
+  const float* xr = x + row * D;
+  float s = 0.f;
+  for (int i = threadIdx.x * 4; i < D; i += NT * 4) {
+    const float4_t v = *reinterpret_cast<const float4_t*>(xr + i);
+    s += v[0] + v[1] + v[2] + v[3];
+  }
+  const float mean = block_sum<NW>(s, red) / D;
+  float ss = 0.f;
+  for (int i = threadIdx.x * 4; i < D; i += NT * 4) {
+    const float4_t v = *reinterpret_cast<const float4_t*>(xr + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ss += (v[e] - mean) * (v[e] - mean);
+  }
+  const float r = rsqrtf(block_sum<NW>(ss, red) / D + eps);
+  for (int i = threadIdx.x * 4; i < D; i += NT * 4) {
+    const float4_t v = *reinterpret_cast<const float4_t*>(xr + i);
+    const float4_t g = *reinterpret_cast<const float4_t*>(w + i);
+    const float4_t bb = *reinterpret_cast<const float4_t*>(b + i);
+    float4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (v[e] - mean) * r * g[e] + bb[e];
+    if (y_f32) *reinterpret_cast<float4_t*>(y_f32 + row * D + i) = o;
+    if (y_bf) {
+      uint2 pk;
+      pk.x = pack_bf2(o[0], o[1]);
+      pk.y = pack_bf2(o[2], o[3]);
+      *reinterpret_cast<uint2*>(y_bf + row * D + i) = pk;
+    }
+  }
+}
+
+// dx = r * (g - mean(g) - xhat * mean(g*xhat)),  g = dy*w   (+ dres)
+__global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                           const float* __restrict__ w, const float* dres, float* dx,
+                                                           bf16_t* dx_bf, int D, float eps) {
+  __shared__ float red[NW];
+  const size_t row = blockIdx.x;
+  const float* xr = x + row * D;
+  const float* gr = dy + row * D;
+  float s = 0.f;
+  for (int i = threadIdx.x * 4; i < D; i += NT * 4) {
+    const float4_t v = *reinterpret_cast<const float4_t*>(xr + i);
+    s += v[0] + v[1] + v[2] + v[3];
+  }
+  const float mean = block_sum<NW>(s, red) / D;
+  float ss = 0.f;
+  for (int i = threadIdx.x * 4; i < D; i += NT * 4) {
+    const float4_t v = *reinterpret_cast<const float4_t*>(xr + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) ss += (v[e] - mean) * (v[e] - mean);
+  }
+  const float r = rsqrtf(block_sum<NW>(ss, red) / D + eps);
+  float sg = 0.f, sgx = 0.f;
+  for (int i = threadIdx.x * 4; i < D; i += NT * 4) {
+    const float4_t v = *reinterpret_cast<const float4_t*>(xr + i);
+    const float4_t g = *reinterpret_cast<const float4_t*>(gr + i);
+    const float4_t ww = *reinterpret_cast<const float4_t*>(w + i);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gg = g[e] * ww[e];
+      sg += gg;
+      sgx += gg * (v[e] - mean) * r;
+    }
+  }
+  sg = block_sum<NW>(sg, red) / D;
+  sgx = block_sum<NW>(sgx, red) / D;
+  for (int i = threadIdx.x * 4; i < D; i += NT * 4) {
+    const float4_t v = *reinterpret_cast<const float4_t*>(xr + i);
+    const float4_t g = *reinterpret_cast<const float4_t*>(gr + i);
+    const float4_t ww = *reinterpret_cast<const float4_t*>(w + i);
+    float4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = r * (g[e] * ww[e] - sg - (v[e] - mean) * r * sgx);
+    if (dres) {
+      const float4_t d = *reinterpret_cast<const float4_t*>(dres + row * D + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] += d[e];
+    }
+    if (dx) *reinterpret_cast<float4_t*>(dx + row * D + i) = o;
+    if (dx_bf) {
+      uint2 pk;
+      pk.x = pack_bf2(o[0], o[1]);
+      pk.y = pack_bf2(o[2], o[3]);
+      *reinterpret_cast<uint2*>(dx_bf + row * D + i) = pk;
+    }
+  }
+}
+
+extern "C" int mh_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, int M, int D, float eps,
+                              hipStream_t stream) {
+  if (M <= 0) return MH_OK;
+  if (D % 4) return MH_ERR_ARG;
+  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(M), dim3(NT), 0, stream, x, w, (bf16_t*)y_bf16, D, eps);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_rmsnorm_bwd(const float* dy, const float* x, const float* w, const float* dres, float* dx,
+                              void* dx_bf16, int M, int D, float eps, hipStream_t stream) {
+  if (M <= 0) return MH_OK;
+  if (D % 4) return MH_ERR_ARG;
+  hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(M), dim3(NT), 0, stream, dy, x, w, dres, dx, (bf16_t*)dx_bf16, D, eps);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, int M,
+                                int D, float eps, hipStream_t stream) {
+  if (M <= 0) return MH_OK;
+  if (D % 4) return MH_ERR_ARG;
+  hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(M), dim3(NT), 0, stream, x, w, b, (bf16_t*)y_bf16, y_f32, D, eps);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_layernorm_bwd(const float* dy, const float* x, const float* w, const float* dres, float* dx,
+                                void* dx_bf16, int M, int D, float eps, hipStream_t stream) {
+  if (M <= 0) return MH_OK;
+  if (D % 4) return MH_ERR_ARG;
+  hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(M), dim3(NT), 0, stream, dy, x, w, dres, dx, (bf16_t*)dx_bf16, D,
+                     eps);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}

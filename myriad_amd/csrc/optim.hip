@@ -1,0 +1,53 @@
+// K15: AdamW on the flat fp32 trainable-parameter buffer (reference runner_base.py:104-139: torch.optim.AdamW,
+// betas (0.9, 0.999), eps 1e-8, decoupled weight decay 0.05 on the wd group / 0 on the no-wd group), with an
+// optional bf16 shadow copy written in the same pass (the copy the next step's MFMA GEMMs read).
+// HBM-bound: 28 B/param algorithmic (read p,g,m,v ; write p,m,v) + 2 B for the shadow.
+#include "common.h"
+
+__global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                             float* __restrict__ v, bf16_t* __restrict__ shadow, long n4, float lr, float beta1,
+                             float beta2, float omb1, float omb2, float eps, float wd, float bc1, float bc2_sqrt,
+                             float gscale) {
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < n4; it += (long)gridDim.x * blockDim.x) {
+    float4_t pp = *reinterpret_cast<const float4_t*>(p + it * 4);
+    const float4_t gg = *reinterpret_cast<const float4_t*>(g + it * 4);
+    float4_t mm = *reinterpret_cast<const float4_t*>(m + it * 4);
+    float4_t vv = *reinterpret_cast<const float4_t*>(v + it * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float gr = gg[e] * gscale;
+      pp[e] *= (1.f - lr * wd);
+      mm[e] = beta1 * mm[e] + omb1 * gr;
+      vv[e] = beta2 * vv[e] + omb2 * gr * gr;
+      const float denom = sqrtf(vv[e]) / bc2_sqrt + eps;
+      pp[e] -= (lr / bc1) * (mm[e] / denom);
+    }
+    *reinterpret_cast<float4_t*>(p + it * 4) = pp;
+    *reinterpret_cast<float4_t*>(m + it * 4) = mm;
+    *reinterpret_cast<float4_t*>(v + it * 4) = vv;
+    if (shadow) {
+      uint2 pk;
+      pk.x = pack_bf2(pp[0], pp[1]);
+      pk.y = pack_bf2(pp[2], pp[3]);
+      *reinterpret_cast<uint2*>(shadow + it * 4) = pk;
+    }
+  }
+}
+
+// step is 1-based.  grad_scale multiplies the gradient first (e.g. 1/world after a sum all-reduce).
+extern "C" int mh_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, float lr,
+                             float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+                             hipStream_t stream) {
+  if (n <= 0) return MH_OK;
+  if (n % 4 || step < 1) return MH_ERR_ARG;
+  // bias corrections and (1-beta) in double on the host, like torch.optim.AdamW
+  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  const float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
+  long grid = (n / 4 + 255) / 256;
+  if (grid > 256 * 16) grid = 256 * 16;
+  hipLaunchKernelGGL(adamw_kernel, dim3((int)grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow_bf16, n / 4, lr,
+                     beta1, beta2, omb1, omb2, eps, weight_decay, bc1, bc2s, grad_scale);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}

@@ -1,0 +1,352 @@
+"""Thin tensor->pointer wrappers over the C ABI (include/myriad_hip.h).  torch is used only for device memory
+and the current HIP stream; all arithmetic happens in libmyriad_hip.so.  No fallbacks."""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+GEMM_OUT_F32 = 1
+GEMM_GELU = 2
+GEMM_REGSTAGE = 4
+
+
+def _L():
+    return _lib.load()
+
+
+def _s() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _chk2d(t: torch.Tensor, dtype, name: str):
+    if t.dtype != dtype or not t.is_cuda or t.dim() != 2 or t.stride(1) != 1:
+        raise _lib.MyriadHipError(f"{name}: need cuda {dtype} 2-D tensor with unit inner stride, got "
+                                  f"{t.dtype} {tuple(t.shape)} strides {t.stride()} cuda={t.is_cuda}")
+
+
+def round_up(x: int, m: int) -> int:
+    return (x + m - 1) // m * m
+
+
+# --------------------------------------------------------------------------- GEMM
+def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+         residual: Optional[torch.Tensor] = None, out_dtype=BF16, gelu: bool = False, alpha: float = 1.0,
+         regstage: bool = False) -> torch.Tensor:
+    """out[M,N] = alpha * a[M,K] @ b[N,K]^T (+bias) (gelu) (+residual f32)."""
+    _chk2d(a, BF16, "gemm.a")
+    _chk2d(b, BF16, "gemm.b")
+    M, K = a.shape
+    N, K2 = b.shape
+    if K != K2:
+        raise _lib.MyriadHipError(f"gemm: K mismatch {K} vs {K2}")
+    if out is None:
+        out = torch.empty((M, N), dtype=out_dtype, device=a.device)
+    else:
+        _chk2d(out, out.dtype, "gemm.out")
+        if out.shape != (M, N):
+            raise _lib.MyriadHipError(f"gemm: out shape {tuple(out.shape)} != {(M, N)}")
+    flags = (GEMM_OUT_F32 if out.dtype == F32 else 0) | (GEMM_GELU if gelu else 0) | (GEMM_REGSTAGE if regstage else 0)
+    if bias is not None and (bias.dtype != F32 or bias.numel() != N):
+        raise _lib.MyriadHipError("gemm: bias must be f32 [N]")
+    ldr = 0
+    if residual is not None:
+        _chk2d(residual, F32, "gemm.residual")
+        ldr = residual.stride(0)
+    rc = _L().mh_gemm_bf16_nt(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, _p(bias),
+                              _p(residual), ldr, flags, float(alpha), _s())
+    _lib.check(rc, f"mh_gemm_bf16_nt M={M} N={N} K={K}")
+    return out
+
+
+# --------------------------------------------------------------------------- attention
+def attn_fwd(q, k, v, H: int, D: int, scale: float, causal: bool = False, bias=None, kv_len=None, out=None,
+             need_lse: bool = True):
+    """q [B,Sq,Wq], k/v [B,Sk,W*] bf16 views (head h at cols h*D..), returns (o [B,Sq,H*D] bf16, lse [B,H,Sq] f32)."""
+    B, Sq = q.shape[0], q.shape[1]
+    Sk = k.shape[1]
+    for t, n in ((q, "q"), (k, "k"), (v, "v")):
+        if t.dtype != BF16 or t.stride(2) != 1:
+            raise _lib.MyriadHipError(f"attn_fwd.{n}: need bf16 with unit inner stride")
+    if out is None:
+        out = torch.empty((B, Sq, H * D), dtype=BF16, device=q.device)
+    lse = torch.empty((B, H, Sq), dtype=F32, device=q.device) if need_lse else None
+    rc = _L().mh_attn_fwd(_p(q), _p(k), _p(v), _p(out), _p(lse), _p(bias), _p(kv_len), B, H, Sq, Sk, D,
+                          q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                          out.stride(0), out.stride(1), float(scale), int(causal), _s())
+    _lib.check(rc, f"mh_attn_fwd B={B} H={H} Sq={Sq} Sk={Sk} D={D}")
+    return out, lse
+
+
+def attn_bwd(q, k, v, o, dout, lse, H: int, D: int, scale: float, causal: bool = False, bias=None, kv_len=None,
+             dq=None, dk=None, dv=None):
+    B, Sq = q.shape[0], q.shape[1]
+    Sk = k.shape[1]
+    dev = q.device
+    if dq is None:
+        dq = torch.empty((B, Sq, H * D), dtype=BF16, device=dev)
+    if dk is None:
+        dk = torch.empty((B, Sk, H * D), dtype=BF16, device=dev)
+    if dv is None:
+        dv = torch.empty((B, Sk, H * D), dtype=BF16, device=dev)
+    delta = torch.empty((B, H, Sq), dtype=F32, device=dev)
+    rc = _L().mh_attn_bwd(_p(q), _p(k), _p(v), _p(o), _p(dout), _p(lse), _p(delta), _p(dq), _p(dk), _p(dv), _p(bias),
+                          _p(kv_len), B, H, Sq, Sk, D, q.stride(0), q.stride(1), k.stride(0), k.stride(1),
+                          v.stride(0), v.stride(1), o.stride(0), o.stride(1), dout.stride(0), dout.stride(1),
+                          dq.stride(0), dq.stride(1), dk.stride(0), dk.stride(1), dv.stride(0), dv.stride(1),
+                          float(scale), int(causal), _s())
+    _lib.check(rc, f"mh_attn_bwd B={B} H={H} Sq={Sq} Sk={Sk} D={D}")
+    return dq, dk, dv
+
+
+# --------------------------------------------------------------------------- norms
+def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, out=None):
+    M, D = x.shape
+    if out is None:
+        out = torch.empty((M, D), dtype=BF16, device=x.device)
+    _lib.check(_L().mh_rmsnorm_fwd(_p(x), _p(w), _p(out), M, D, float(eps), _s()), "mh_rmsnorm_fwd")
+    return out
+
+
+def rmsnorm_bwd(dy, x, w, eps: float, dres=None, want_f32=True, want_bf16=False):
+    M, D = x.shape
+    dx = torch.empty((M, D), dtype=F32, device=x.device) if want_f32 else None
+    dxb = torch.empty((M, D), dtype=BF16, device=x.device) if want_bf16 else None
+    _lib.check(_L().mh_rmsnorm_bwd(_p(dy), _p(x), _p(w), _p(dres), _p(dx), _p(dxb), M, D, float(eps), _s()),
+               "mh_rmsnorm_bwd")
+    return dx, dxb
+
+
+def layernorm_fwd(x, w, b, eps: float, want_bf16=True, want_f32=False):
+    M, D = x.shape
+    yb = torch.empty((M, D), dtype=BF16, device=x.device) if want_bf16 else None
+    yf = torch.empty((M, D), dtype=F32, device=x.device) if want_f32 else None
+    _lib.check(_L().mh_layernorm_fwd(_p(x), _p(w), _p(b), _p(yb), _p(yf), M, D, float(eps), _s()), "mh_layernorm_fwd")
+    return yb, yf
+
+
+def layernorm_bwd(dy, x, w, eps: float, dres=None, want_f32=True, want_bf16=False):
+    M, D = x.shape
+    dx = torch.empty((M, D), dtype=F32, device=x.device) if want_f32 else None
+    dxb = torch.empty((M, D), dtype=BF16, device=x.device) if want_bf16 else None
+    _lib.check(_L().mh_layernorm_bwd(_p(dy), _p(x), _p(w), _p(dres), _p(dx), _p(dxb), M, D, float(eps), _s()),
+               "mh_layernorm_bwd")
+    return dx, dxb
+
+
+# --------------------------------------------------------------------------- elementwise
+def rope_(x2d: torch.Tensor, col0: int, n_heads: int, head_dim: int, pos: torch.Tensor, cos, sin, sign: float = 1.0):
+    n_tok = x2d.shape[0]
+    _lib.check(_L().mh_rope_inplace(_p(x2d), x2d.stride(0), col0, n_tok, n_heads, head_dim, _p(pos), _p(cos), _p(sin),
+                                    float(sign), _s()), "mh_rope_inplace")
+    return x2d
+
+
+def silu_mul_fwd(gu: torch.Tensor):
+    M, I2 = gu.shape
+    h = torch.empty((M, I2 // 2), dtype=BF16, device=gu.device)
+    _lib.check(_L().mh_silu_mul_fwd(_p(gu), _p(h), M, I2 // 2, _s()), "mh_silu_mul_fwd")
+    return h
+
+
+def silu_mul_bwd(dh: torch.Tensor, gu: torch.Tensor):
+    M, I2 = gu.shape
+    dgu = torch.empty_like(gu)
+    _lib.check(_L().mh_silu_mul_bwd(_p(dh), _p(gu), _p(dgu), M, I2 // 2, _s()), "mh_silu_mul_bwd")
+    return dgu
+
+
+def gelu_fwd(x):
+    y = torch.empty_like(x)
+    _lib.check(_L().mh_gelu_fwd(_p(x), _p(y), x.numel(), _s()), "mh_gelu_fwd")
+    return y
+
+
+def gelu_bwd(dy, x):
+    dx = torch.empty_like(x)
+    _lib.check(_L().mh_gelu_bwd(_p(dy), _p(x), _p(dx), x.numel(), _s()), "mh_gelu_bwd")
+    return dx
+
+
+def to_bf16(x: torch.Tensor, out=None):
+    if out is None:
+        out = torch.empty(x.shape, dtype=BF16, device=x.device)
+    _lib.check(_L().mh_cast_f32_to_bf16(_p(x), _p(out), x.numel(), _s()), "mh_cast_f32_to_bf16")
+    return out
+
+
+def to_f32(x: torch.Tensor, out=None):
+    if out is None:
+        out = torch.empty(x.shape, dtype=F32, device=x.device)
+    _lib.check(_L().mh_cast_bf16_to_f32(_p(x), _p(out), x.numel(), _s()), "mh_cast_bf16_to_f32")
+    return out
+
+
+def transpose_to_bf16(x2d: torch.Tensor, pad_to: int = 64, out=None):
+    """[R,C] (f32 or bf16) -> [C, round_up(R,pad_to)] bf16, zero padded."""
+    R, C = x2d.shape
+    ldo = round_up(R, pad_to)
+    if out is None:
+        out = torch.empty((C, ldo), dtype=BF16, device=x2d.device)
+    _lib.check(_L().mh_transpose_to_bf16(_p(x2d), int(x2d.dtype == F32), x2d.stride(0), _p(out), out.stride(0), R, C,
+                                         _s()), "mh_transpose_to_bf16")
+    return out
+
+
+def copy2d(src: torch.Tensor, dst: torch.Tensor, accumulate: bool = False):
+    rows, cols = src.shape
+    _lib.check(_L().mh_copy2d_f32(_p(src), src.stride(0), _p(dst), dst.stride(0), rows, cols, int(accumulate), _s()),
+               "mh_copy2d_f32")
+    return dst
+
+
+def copy3d(src: torch.Tensor, dst: torch.Tensor, accumulate: bool = False):
+    nb, rows, cols = src.shape
+    _lib.check(_L().mh_copy3d_f32(_p(src), src.stride(0), src.stride(1), _p(dst), dst.stride(0), dst.stride(1), nb,
+                                  rows, cols, int(accumulate), _s()), "mh_copy3d_f32")
+    return dst
+
+
+def embed_gather(table: torch.Tensor, ids: torch.Tensor, out: torch.Tensor, dst_rows: Optional[torch.Tensor] = None):
+    """out[dst_rows[i]] = f32(table[ids[i]]); out is a 2-D f32 view."""
+    n = ids.numel()
+    D = table.shape[1]
+    _lib.check(_L().mh_embed_gather(_p(table), _p(ids), _p(dst_rows), _p(out), n, D, out.stride(0), _s()),
+               "mh_embed_gather")
+    return out
+
+
+def gather_rows_bf16(src: torch.Tensor, rows: torch.Tensor):
+    n, D = rows.numel(), src.shape[1]
+    out = torch.empty((n, D), dtype=BF16, device=src.device)
+    _lib.check(_L().mh_gather_rows_f32_to_bf16(_p(src), src.stride(0), _p(rows), _p(out), n, D, _s()),
+               "mh_gather_rows_f32_to_bf16")
+    return out
+
+
+def scatter_rows(src: torch.Tensor, rows: torch.Tensor, dst: torch.Tensor, accumulate: bool = False):
+    n, D = src.shape
+    _lib.check(_L().mh_scatter_rows_f32(_p(src), _p(rows), _p(dst), dst.stride(0), n, D, int(accumulate), _s()),
+               "mh_scatter_rows_f32")
+    return dst
+
+
+def colsum(x2d: torch.Tensor):
+    R, C = x2d.shape
+    out = torch.empty((C,), dtype=F32, device=x2d.device)
+    _lib.check(_L().mh_colsum_f32(_p(x2d), x2d.stride(0), _p(out), R, C, _s()), "mh_colsum_f32")
+    return out
+
+
+def scale_(x: torch.Tensor, a: float):
+    _lib.check(_L().mh_scale_f32(_p(x), float(a), x.numel(), _s()), "mh_scale_f32")
+    return x
+
+
+# --------------------------------------------------------------------------- low-rank adaptor
+def lowrank_fwd(x, A, Bm):
+    M, D = x.shape
+    R = A.shape[0]
+    y = torch.empty_like(x)
+    t = torch.empty((M, R), dtype=F32, device=x.device)
+    _lib.check(_L().mh_lowrank_fwd(_p(x), _p(A), _p(Bm), _p(y), _p(t), M, D, R, _s()), "mh_lowrank_fwd")
+    return y, t
+
+
+def lowrank_bwd(dy, x, t, A, Bm, dA, dB, need_dx=False):
+    M, D = x.shape
+    R = A.shape[0]
+    ws = torch.empty((_L().mh_lowrank_bwd_ws_floats(M, D, R),), dtype=F32, device=x.device)
+    dx = torch.empty_like(x) if need_dx else None
+    _lib.check(_L().mh_lowrank_bwd(_p(dy), _p(x), _p(t), _p(A), _p(Bm), _p(dA), _p(dB), _p(dx), _p(ws), M, D, R, _s()),
+               "mh_lowrank_bwd")
+    return dx
+
+
+# --------------------------------------------------------------------------- loss / decode
+def clamp_ce(logits: torch.Tensor, labels: torch.Tensor, grad_scale: float, want_grad: bool = True, ldd: int = 0):
+    R, V = logits.shape
+    row_loss = torch.empty((R,), dtype=F32, device=logits.device)
+    dlog = None
+    if want_grad:
+        ldd = ldd or round_up(V, 64)
+        dlog = torch.empty((R, ldd), dtype=BF16, device=logits.device)
+    _lib.check(_L().mh_clamp_ce(_p(logits), logits.stride(0), _p(labels), _p(row_loss), _p(dlog), ldd, R, V,
+                                float(grad_scale), _s()), "mh_clamp_ce")
+    return row_loss, dlog
+
+
+def sum_f32(x: torch.Tensor, scale: float = 1.0):
+    out = torch.empty((1,), dtype=F32, device=x.device)
+    _lib.check(_L().mh_sum_f32(_p(x), _p(out), x.numel(), float(scale), _s()), "mh_sum_f32")
+    return out
+
+
+def argmax_rows(logits: torch.Tensor, ban_id: int = -1, want_margin: bool = False):
+    R, V = logits.shape
+    out = torch.empty((R,), dtype=torch.long, device=logits.device)
+    margin = torch.empty((R,), dtype=F32, device=logits.device) if want_margin else None
+    _lib.check(_L().mh_argmax_rows(_p(logits), logits.stride(0), _p(out), _p(margin), R, V, ban_id, _s()),
+               "mh_argmax_rows")
+    return (out, margin) if want_margin else out
+
+
+# --------------------------------------------------------------------------- conv stack pieces
+def im2col(x_nhwc: torch.Tensor, kh: int, kw: int, pad: int):
+    B, H, W, C = x_nhwc.shape
+    OH, OW = H + 2 * pad - kh + 1, W + 2 * pad - kw + 1
+    Kpad = round_up(kh * kw * C + 1, 64)
+    col = torch.empty((B * OH * OW, Kpad), dtype=BF16, device=x_nhwc.device)
+    _lib.check(_L().mh_im2col_nhwc(_p(x_nhwc), _p(col), B, H, W, C, kh, kw, pad, Kpad, _s()), "mh_im2col_nhwc")
+    return col
+
+
+def col2im(dcol: torch.Tensor, B, H, W, C, kh, kw, pad):
+    dx = torch.empty((B, H, W, C), dtype=F32, device=dcol.device)
+    _lib.check(_L().mh_col2im_nhwc(_p(dcol), _p(dx), B, H, W, C, kh, kw, pad, dcol.stride(0), _s()), "mh_col2im_nhwc")
+    return dx
+
+
+def relu_pool_fwd(y2d: torch.Tensor, B, H, W, C):
+    p = torch.empty((B, H // 2, W // 2, C), dtype=BF16, device=y2d.device)
+    _lib.check(_L().mh_relu_maxpool2_fwd(_p(y2d), y2d.stride(0), _p(p), B, H, W, C, _s()), "mh_relu_maxpool2_fwd")
+    return p
+
+
+def relu_pool_bwd(dp: torch.Tensor, y2d: torch.Tensor, B, H, W, C):
+    dy = torch.empty((B * H * W, C), dtype=BF16, device=y2d.device)
+    _lib.check(_L().mh_relu_maxpool2_bwd(_p(dp), _p(y2d), y2d.stride(0), _p(dy), dy.stride(0), B, H, W, C, _s()),
+               "mh_relu_maxpool2_bwd")
+    return dy
+
+
+def conv_pack(Wm: torch.Tensor, bias: Optional[torch.Tensor], out=None):
+    Cout, K = Wm.shape
+    Kpad = round_up(K + 1, 64)
+    if out is None:
+        out = torch.empty((Cout, Kpad), dtype=BF16, device=Wm.device)
+    _lib.check(_L().mh_conv_pack_weight(_p(Wm), _p(bias), _p(out), Cout, K, Kpad, _s()), "mh_conv_pack_weight")
+    return out
+
+
+def conv_unpack_grad(dWp: torch.Tensor, dW: torch.Tensor, db: Optional[torch.Tensor]):
+    Cout, Kpad = dWp.shape
+    K = dW.shape[1]
+    _lib.check(_L().mh_conv_unpack_grad(_p(dWp), _p(dW), _p(db), Cout, K, Kpad, _s()), "mh_conv_unpack_grad")
+
+
+# --------------------------------------------------------------------------- optimiser
+def adamw_step(p, g, m, v, lr, wd, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0, shadow=None):
+    _lib.check(_L().mh_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), float(beta1),
+                                  float(beta2), float(eps), float(wd), int(step), float(grad_scale), _s()),
+               "mh_adamw_step")

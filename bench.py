@@ -1,0 +1,281 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/s of one Myriad fine-tune step (EVA-ViT-g -> Q-Former + vision-expert adapters ->
+Vicuna-7B, fwd + dgrad/wgrad bwd + gradient all-reduce + AdamW) on N MI355X GPUs, data parallel (weak scaling,
+fixed per-GPU batch).  Prints ONE JSON line on rank 0.
+
+  python bench.py --gpus 1 --steps 5 --warmup 2
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Synthetic data and seeded random weights of the real architecture: no dataset / checkpoint exists in
+the environment.  Nothing here reads /root/reference.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+PEAK_BF16_TFLOPS = 2500.0   # MI355X dense bf16 MFMA (guides/MI355X_MICROARCH.md)
+
+
+def flops_per_sample(arch: str, stage: int, cfg: dict, n_before=4, n_after=28, n_tgt=16) -> dict:
+    """Algorithmic FLOPs per sample per training step, SURVEY 8(d) formulas (1 MAC = 2 FLOP)."""
+    Dv, Hv, dv = cfg["vit_dim"], cfg["vit_hidden"], cfg["vit_depth"]
+    N = (cfg["image_size"] // cfg["patch"]) ** 2 + 1
+    f_vit = dv * (2 * N * (4 * Dv * Dv + 2 * Dv * Hv) + 4 * N * N * Dv) + 2 * (N - 1) * 3 * cfg["patch"] ** 2 * Dv
+    nq = cfg["num_query_token"] + (49 if (arch == "myriad" and stage in (1, 2)) else 0)
+    Q, QI, ql = cfg["qf_dim"], cfg["qf_inter"], cfg["qf_layers"]
+    f_qf = ql * (2 * nq * 4 * Q * Q + 4 * nq * nq * Q + 4 * nq * Q * QI) + (ql // 2) * (
+        4 * nq * Q * Q + 4 * N * Dv * Q + 4 * nq * N * Q)
+    L, LI, ll, V = cfg["llm_dim"], cfg["llm_inter"], cfg["llm_layers"], cfg["vocab"]
+    n_img = nq + (18 if (arch == "myriad" and stage in (0, 1)) else 0)
+    S = 1 + n_before + n_img + n_after + n_tgt
+    f_llm = 2 * S * ll * (4 * L * L + 3 * L * LI) + 4 * S * S * L * ll + 2 * S * L * V
+    f_proj = 2 * nq * Q * L
+    f_ve = 0.0
+    if arch == "myriad":
+        stem = sum(2 * 9 * ci * co * hw * hw for (ci, co), hw in zip([(1, 4), (4, 16), (16, 64), (64, 256), (256, 1024)],
+                                                                       [224, 112, 56, 28, 14]))
+        if stage in (1, 2):
+            f_ve += stem + 2 * 49 * 1024 * Q
+        if stage in (0, 1):
+            f_ve += stem + 2 * 9 * 25 * 1024 * L
+    total = f_vit + 2 * (f_qf + f_proj + f_llm) + 3 * f_ve
+    return dict(total=total, S=S, n_img=n_img, vit=f_vit, qformer=f_qf, llm=f_llm, ve=f_ve)
+
+
+def make_samples(B: int, vocab: int, seed: int, device):
+    g = torch.Generator().manual_seed(seed)
+    image = torch.randn(B, 3, 224, 224, generator=g)
+    maps = torch.rand(B, 1, 224, 224, generator=g)
+    before = torch.randint(3, vocab, (1, 4), generator=g).expand(B, -1).contiguous()
+    after = torch.randint(3, vocab, (1, 28), generator=g).expand(B, -1).contiguous()
+    tgt = torch.randint(3, vocab, (B, 16), generator=g)
+    return dict(image=image.to(device), anomaly_maps=maps.to(device), oneshot_anomaly_maps=maps.to(device),
+                before_ids=before, after_ids=after, target_ids=tgt, target_mask=torch.ones(B, 16, dtype=torch.long))
+
+
+class GemmProbe:
+    """Times every launch of the dominant kernel (mh_gemm_bf16_nt) with HIP events on the launch stream."""
+
+    def __init__(self):
+        from myriad_amd import ops
+        self.ops = ops
+        self.orig = ops.gemm
+        self.records = []
+
+    def __enter__(self):
+        ops = self.ops
+
+        def timed(a, b, *args, **kw):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = self.orig(a, b, *args, **kw)
+            e1.record()
+            self.records.append((e0, e1, 2.0 * a.shape[0] * b.shape[0] * a.shape[1]))
+            return out
+
+        ops.gemm = timed
+        for mod in ("llama", "qformer", "eva_vit", "networks", "myriad"):
+            m = sys.modules.get("myriad_amd." + mod)
+            if m is not None and hasattr(m, "ops"):
+                pass   # modules call ops.gemm through the module attribute, so patching ops is enough
+        return self
+
+    def __exit__(self, *exc):
+        self.ops.gemm = self.orig
+
+    def summary(self):
+        torch.cuda.synchronize()
+        t_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
+        fl = sum(f for _, _, f in self.records)
+        n = len(self.records)
+        return dict(launches=n, total_ms=t_ms, avg_us=1e3 * t_ms / max(n, 1), tflops=fl / (t_ms * 1e-3) / 1e12 if t_ms else 0.0,
+                    flops=fl)
+
+
+def cpu_baseline(arch: str, stage: int, cfg: dict, budget_note: str = "") -> dict:
+    """Reference-equivalent CPU path (the oracle, pinned to the reference's modules by tests/golden) timed on the
+    host cores on a bounded sample: full width, reduced depth, B=1; per-component times are scaled linearly to the
+    full depth (ViT 39 blocks fwd; Q-Former 12 layers, LLaMA 32 layers, VE nets fwd+bwd)."""
+    from oracle import myriad_ref as R
+    from tests import golden_utils as gu
+    torch.manual_seed(0)
+    nth = torch.get_num_threads()
+    kv, kq, kl = 2, 2, 1
+    V = 2048
+    sd = {}
+    sd.update(gu.vit_weights(cfg["vit_dim"], kv, cfg["vit_heads"], cfg["vit_hidden"], cfg["patch"], 257, seed=1))
+    sd.update(gu.qformer_weights(cfg["qf_dim"], kq, cfg["qf_inter"], cfg["vit_dim"], seed=2))
+    sd.update(gu.llama_weights(cfg["llm_dim"], kl, cfg["llm_inter"], V, seed=3))
+    sd.update(gu.adapter_weights(seed=4))
+    sd.update(gu.glue_weights(seed=5))
+    train = [k for k in sd if k.startswith(("expert_adaptor.", "VEInstructor.", "VETokenizer."))]
+    for k in train:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    image, maps, before, after, tgt, tmask = gu.synthetic_batch(1, V, seed=6)
+    t = {}
+
+    def clock(name, fn):
+        t0 = time.perf_counter()
+        out = fn()
+        t[name] = time.perf_counter() - t0
+        return out
+
+    with torch.no_grad():
+        x = clock("vit", lambda: R.vit_forward(sd, image, cfg["vit_heads"]))
+    x = R.ln_vision(sd, R.lora_adaptor(sd, x) if arch == "myriad" else x)
+    q = sd["query_tokens"].expand(1, -1, -1)
+    if arch == "myriad" and stage in (1, 2):
+        q = torch.cat([q, clock("ve_ins_f", lambda: R.ve_instructor(sd, maps))], 1)
+    qo = clock("qf_f", lambda: R.qformer_forward(sd, q, x, cfg["qf_heads"]))
+    img = torch.nn.functional.linear(qo, sd["llama_proj.weight"], sd["llama_proj.bias"])
+    if arch == "myriad" and stage in (0, 1):
+        img = torch.cat([img, clock("ve_tok_f", lambda: R.ve_tokenizer(sd, maps))], 1)
+    ew = sd["llama_model.model.embed_tokens.weight"]
+    emb, attn, labels = R.assemble_inputs(ew, img, before, after, tgt, tmask, 1, 2)
+    loss = clock("llm_f", lambda: R.llama_causal_lm(sd, emb, attn, labels, cfg["llm_heads"])[0])
+    clock("bwd_all", lambda: loss.backward())
+    # backward time is attributed proportionally to forward time of the differentiable parts
+    f_parts = {k: v for k, v in t.items() if k not in ("vit", "bwd_all")}
+    fsum = sum(f_parts.values())
+    scale = dict(vit=cfg["vit_depth"] / kv, qf_f=cfg["qf_layers"] / kq, llm_f=cfg["llm_layers"] / kl, ve_ins_f=1.0,
+                 ve_tok_f=1.0)
+    total = t["vit"] * scale["vit"]
+    for k, v in f_parts.items():
+        total += (v + t["bwd_all"] * v / fsum) * scale[k]
+    n_train = sum(sd[k].numel() for k in train)
+    total += n_train * 28 / 5e9   # AdamW on the host at ~5 GB/s effective (measured class of stream rate on one socket)
+    return dict(value=1.0 / total, unit="images/s", cores=nth, kind="port",
+                sample=f"oracle (CPU restatement pinned to the reference modules) fp32 B=1 {arch} stage {stage}: "
+                       f"ViT {kv}/{cfg['vit_depth']} blocks, Q-Former {kq}/{cfg['qf_layers']}, LLaMA {kl}/"
+                       f"{cfg['llm_layers']} layers timed fwd+bwd and scaled linearly to full depth "
+                       f"({sum(t.values()):.1f} s measured, {total:.1f} s/step extrapolated)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=8, help="per-GPU images per step (reference: 4 + 4 augmented)")
+    ap.add_argument("--arch", default="myriad", choices=["myriad", "mini_gpt4"])
+    ap.add_argument("--stage", type=int, default=1)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--llm-layers", type=int, default=32)
+    ap.add_argument("--vit-depth", type=int, default=39)
+    ap.add_argument("--qf-layers", type=int, default=12)
+    ap.add_argument("--b1", action="store_true", help="also time config[1] (batch 1) and report it as config1_b1")
+    a = ap.parse_args()
+
+    from myriad_amd import _lib
+    from myriad_amd.myriad import MiniGPT4HIP, MyriadHIP
+    from myriad_amd.runner import DataParallel, LinearWarmupCosineLRScheduler, init_distributed, setup_seeds
+    from myriad_amd.synthetic import SyntheticWeights, full_config
+
+    _lib.load()   # fail loudly if the HIP library is missing
+    rank, world, local = init_distributed()
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU path exists for the product)")
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+    setup_seeds(42, rank)                                  # reference train.py:63-72
+    cfg = full_config(llm_layers=a.llm_layers, vit_depth=a.vit_depth, qf_layers=a.qf_layers)
+    weights = SyntheticWeights(cfg, dev, seed=0, arch=a.arch)   # identical frozen weights on every rank
+    cls = MyriadHIP if a.arch == "myriad" else MiniGPT4HIP
+    t0 = time.time()
+    model = cls(weights, dict(fixed_stage=a.stage, fixed_taskstage=0, vit_heads=cfg["vit_heads"], qf_heads=cfg["qf_heads"],
+                              llm_heads=cfg["llm_heads"]), device=dev)
+    torch.cuda.synchronize()
+    build_s = time.time() - t0
+    dp = DataParallel(dev)
+    sched = LinearWarmupCosineLRScheduler(None, max_epoch=10, iters_per_epoch=1600, min_lr=0.0, init_lr=1e-4,
+                                          warmup_steps=0, warmup_start_lr=1e-6)   # shipped recipe
+    samples = make_samples(a.batch, cfg["vocab"], 42 + rank, dev)
+    allreduce = dp.allreduce if world > 1 else None
+
+    def step(i, smp=samples):
+        return model.train_step(smp, sched.step(0, i), 0.05, allreduce=allreduce, world=world)
+
+    for i in range(a.warmup):
+        step(i)
+    dp.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        loss = step(a.warmup + i)
+    dp.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+    dt = float(tt.item())
+    ms_per_step = 1e3 * dt / a.steps
+    value = a.batch * world * a.steps / dt
+
+    fl = flops_per_sample(a.arch, a.stage, cfg)
+    roof = None
+    if not a.no_probe and rank == 0:
+        with GemmProbe() as pr:
+            step(a.warmup + a.steps)
+            gs = pr.summary()
+        roof = dict(bound="mfma", kernel="gemm_nt_kernel<glds> (mh_gemm_bf16_nt)", achieved=round(gs["tflops"], 1),
+                    peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(gs["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=None,
+                    launches_per_step=gs["launches"], avg_launch_us=round(gs["avg_us"], 2),
+                    gemm_ms_per_step=round(gs["total_ms"], 2), gemm_flops_per_step=gs["flops"],
+                    step_algorithmic_tflops=round(a.batch * fl["total"] / (ms_per_step * 1e-3) / 1e12, 1),
+                    step_frac_of_peak=round(a.batch * fl["total"] / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4))
+    extra = {}
+    if a.b1 and rank == 0 and world == 1:
+        s1 = make_samples(1, cfg["vocab"], 42, dev)
+        for i in range(2):
+            step(i, s1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(3):
+            step(i, s1)
+        torch.cuda.synchronize()
+        d1 = (time.perf_counter() - t0) / 3
+        extra["config1_b1"] = dict(value=round(1.0 / d1, 2), ms_per_step=round(1e3 * d1, 2))
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        cpu = cpu_baseline(a.arch, a.stage, cfg)
+        cpu["value"] = round(cpu["value"], 4)
+    if rank == 0:
+        out = {
+            "metric": "images/sec fine-tune step (Vicuna-7B + LoRA-style adapters, 224px)", "value": round(value, 2),
+            "unit": "images/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(ms_per_step, 2),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": f"Myriad fine-tune step ({a.arch}, prompt stage {a.stage}): EVA-ViT-g/14 {cfg['vit_depth']}L "
+                                   f"+ Q-Former {cfg['qf_layers']}L + adapters + Vicuna-7B {cfg['llm_layers']}L, fwd+bwd+AdamW; "
+                                   f"224x224 image, 32-token prompt, 16-token target, S={fl['S']}",
+                       "per_gpu_batch": a.batch, "global_batch": a.batch * world, "seq_len": fl["S"],
+                       "parallelism": f"dp{world}", "trainable_params": model.store.n_params(),
+                       "algorithmic_tflop_per_sample": round(fl["total"] / 1e12, 3)},
+            "loss": round(float(loss), 4), "model_build_s": round(build_s, 1),
+        }
+        if roof is not None:
+            out["roofline"] = roof
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
+        out.update(extra)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -35,6 +35,12 @@ typedef struct ihipStream_t* mh_stream_t; /* == hipStream_t */
 int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                     const float* bias, const float* residual, int ldr, int flags, float alpha, mh_stream_t s);
 
+/* split-K variant (f32 out, no epilogue) for skinny outputs with a long reduction (conv-stem wgrad):
+ * ws holds mh_gemm_splitk_ws_floats(M,N,splits) floats; fixed-order reduction -> deterministic. */
+long mh_gemm_splitk_ws_floats(int M, int N, int splits);
+int mh_gemm_bf16_nt_splitk(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N, int K,
+                           int splits, float* ws, mh_stream_t s);
+
 /* K3/K4/K5 fused attention.  q/k/v/o token-major [B,S,ld] bf16, head h at columns [h*D,(h+1)*D); D in
  * {<=64, <=96 (88), <=128}; lse [B,H,Sq] f32; bias optional additive [H,Sq,Sk] f32 (eva_vit.py:131-140);
  * kv_len optional [B] valid-key counts (right padding, modeling_llama.py:43-54); causal aligns the last query
@@ -90,9 +96,9 @@ int mh_im2col_nhwc(const void* x, void* col, int B, int H, int W, int C, int kh,
                    mh_stream_t s);
 int mh_col2im_nhwc(const void* dcol, float* dx, int B, int H, int W, int C, int kh, int kw, int pad, int Kpad,
                    mh_stream_t s);
-int mh_relu_maxpool2_fwd(const void* y, long ldy, void* p, int B, int H, int W, int C, mh_stream_t s);
-int mh_relu_maxpool2_bwd(const float* dp, const void* y, long ldy, void* dy, long lddy, int B, int H, int W, int C,
-                         mh_stream_t s);
+int mh_relu_maxpool2_fwd(const void* y, int y_is_f32, long ldy, void* p, int B, int H, int W, int C, mh_stream_t s);
+int mh_relu_maxpool2_bwd(const float* dp, const void* y, int y_is_f32, long ldy, void* dy, long lddy, int B, int H,
+                         int W, int C, mh_stream_t s);
 int mh_conv_pack_weight(const float* W, const float* bias, void* Wp, int Cout, int K, int Kpad, mh_stream_t s);
 int mh_conv_unpack_grad(const float* dWp, float* dW, float* db, int Cout, int K, int Kpad, mh_stream_t s);
 
@@ -104,6 +110,11 @@ int mh_copy2d_f32(const float* src, long lds, float* dst, long ldd, long rows, i
 int mh_copy3d_f32(const float* src, long src_bstride, long lds, float* dst, long dst_bstride, long ldd, int nb,
                   long rows, int cols, int accumulate, mh_stream_t s);
 int mh_gather_rows_f32_to_bf16(const float* src, long lds, const int* rows, void* dst, long n, int D, mh_stream_t s);
+int mh_gather_rows_f32(const float* src, long lds, const int* rows, float* dst, long n, int D, mh_stream_t s);
+int mh_copy3d_bf16(const void* src, long src_bstride, long lds, void* dst, long dst_bstride, long ldd, int nb,
+                   long rows, int cols, mh_stream_t s);
+/* K14 patch embedding operand (eva_vit.py:196-204): NCHW f32 image -> [B*np, Kpad] bf16 in (c,iy,ix) order */
+int mh_patchify_nchw(const float* img, void* out, int B, int C, int H, int W, int P, int Kpad, mh_stream_t s);
 int mh_scatter_rows_f32(const float* src, const int* rows, float* dst, long ldd, long n, int D, int accumulate,
                         mh_stream_t s);
 int mh_cast_f32_to_bf16(const float* x, void* y, long n, mh_stream_t s);
@@ -113,8 +124,8 @@ int mh_colsum_f32(const float* in, long ld, float* out, long R, int C, mh_stream
 int mh_scale_f32(float* x, float a, long n, mh_stream_t s);
 
 /* K15 AdamW (runner_base.py:104-139) on a flat f32 buffer with optional bf16 shadow; step is 1-based. */
-int mh_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, float lr, float beta1,
-                  float beta2, float eps, float weight_decay, int step, float grad_scale, mh_stream_t s);
+int mh_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, double lr, double beta1,
+                  double beta2, double eps, double weight_decay, int step, double grad_scale, mh_stream_t s);
 
 /* library identity */
 const char* mh_version(void);

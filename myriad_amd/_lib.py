@@ -11,7 +11,7 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmyriad_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "myriad_hip.h")
 
-_CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float}
+_CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double}
 
 
 class MyriadHipError(RuntimeError):

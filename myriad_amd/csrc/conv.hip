@@ -92,9 +92,18 @@ extern "C" int mh_col2im_nhwc(const void* dcol, float* dx, int B, int H, int W, 
   return MH_OK;
 }
 
-// ReLU -> MaxPool2d(2) on NHWC bf16 (reference networks.py:100-102 etc.).  ldy = row stride of y in
-// elements (the conv GEMM may write into a wider buffer).
-__global__ void relu_pool_fwd_kernel(const bf16_t* __restrict__ y, long ldy, bf16_t* __restrict__ p, int B, int H,
+// ReLU -> MaxPool2d(2) on NHWC (reference networks.py:100-102 etc.).  The conv pre-activation y is kept in
+// fp32 (bf16 would create arg-max ties inside the 2x2 windows and route gradients differently from the fp32
+// reference); the pooled output feeding the next MFMA GEMM is bf16.  ldy = row stride of y in elements.
+template <typename T>
+__device__ __forceinline__ float ldf(const T* p, long i);
+template <>
+__device__ __forceinline__ float ldf<float>(const float* p, long i) { return p[i]; }
+template <>
+__device__ __forceinline__ float ldf<bf16_t>(const bf16_t* p, long i) { return bf2f(p[i]); }
+
+template <typename T>
+__global__ void relu_pool_fwd_kernel(const T* __restrict__ y, long ldy, bf16_t* __restrict__ p, int B, int H,
                                      int W, int C) {
   const int PH = H >> 1, PW = W >> 1;
   const long total = (long)B * PH * PW * C;
@@ -106,16 +115,17 @@ __global__ void relu_pool_fwd_kernel(const bf16_t* __restrict__ y, long ldy, bf1
     const int b = (int)(q / ((long)PW * PH));
     const long base = ((long)b * H + 2 * py) * W + 2 * px;
     float m = 0.f;  // relu floor
-    m = fmaxf(m, bf2f(y[base * ldy + c]));
-    m = fmaxf(m, bf2f(y[(base + 1) * ldy + c]));
-    m = fmaxf(m, bf2f(y[(base + W) * ldy + c]));
-    m = fmaxf(m, bf2f(y[(base + W + 1) * ldy + c]));
+    m = fmaxf(m, ldf<T>(y, base * ldy + c));
+    m = fmaxf(m, ldf<T>(y, (base + 1) * ldy + c));
+    m = fmaxf(m, ldf<T>(y, (base + W) * ldy + c));
+    m = fmaxf(m, ldf<T>(y, (base + W + 1) * ldy + c));
     p[it] = f2bf(m);
   }
 }
 
-// gradient goes to the first arg-max of the window (scan order) iff that max is > 0
-__global__ void relu_pool_bwd_kernel(const float* __restrict__ dp, const bf16_t* __restrict__ y, long ldy,
+// gradient goes to the first arg-max of the window (scan order, like torch) iff that max is > 0
+template <typename T>
+__global__ void relu_pool_bwd_kernel(const float* __restrict__ dp, const T* __restrict__ y, long ldy,
                                      bf16_t* __restrict__ dy, long lddy, int B, int H, int W, int C) {
   const int PH = H >> 1, PW = W >> 1;
   const long total = (long)B * PH * PW * C;
@@ -127,11 +137,11 @@ __global__ void relu_pool_bwd_kernel(const float* __restrict__ dp, const bf16_t*
     const int b = (int)(q / ((long)PW * PH));
     const long base = ((long)b * H + 2 * py) * W + 2 * px;
     const long idx[4] = {base, base + 1, base + W, base + W + 1};
-    float best = bf2f(y[idx[0] * ldy + c]);
+    float best = ldf<T>(y, idx[0] * ldy + c);
     int arg = 0;
 #pragma unroll
     for (int e = 1; e < 4; ++e) {
-      const float v = bf2f(y[idx[e] * ldy + c]);
+      const float v = ldf<T>(y, idx[e] * ldy + c);
       if (v > best) { best = v; arg = e; }
     }
     const float g = best > 0.f ? dp[it] : 0.f;
@@ -140,19 +150,27 @@ __global__ void relu_pool_bwd_kernel(const float* __restrict__ dp, const bf16_t*
   }
 }
 
-extern "C" int mh_relu_maxpool2_fwd(const void* y, long ldy, void* p, int B, int H, int W, int C,
+extern "C" int mh_relu_maxpool2_fwd(const void* y, int y_is_f32, long ldy, void* p, int B, int H, int W, int C,
                                     hipStream_t stream) {
   if ((H & 1) || (W & 1)) return MH_ERR_ARG;
-  hipLaunchKernelGGL(relu_pool_fwd_kernel, dim3(cv_grid((long)B * (H / 2) * (W / 2) * C)), dim3(CV_NT), 0, stream,
-                     (const bf16_t*)y, ldy, (bf16_t*)p, B, H, W, C);
+  const dim3 grid(cv_grid((long)B * (H / 2) * (W / 2) * C)), block(CV_NT);
+  if (y_is_f32)
+    hipLaunchKernelGGL(relu_pool_fwd_kernel<float>, grid, block, 0, stream, (const float*)y, ldy, (bf16_t*)p, B, H, W, C);
+  else
+    hipLaunchKernelGGL(relu_pool_fwd_kernel<bf16_t>, grid, block, 0, stream, (const bf16_t*)y, ldy, (bf16_t*)p, B, H, W, C);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
-extern "C" int mh_relu_maxpool2_bwd(const float* dp, const void* y, long ldy, void* dy, long lddy, int B, int H, int W,
-                                    int C, hipStream_t stream) {
+extern "C" int mh_relu_maxpool2_bwd(const float* dp, const void* y, int y_is_f32, long ldy, void* dy, long lddy, int B,
+                                    int H, int W, int C, hipStream_t stream) {
   if ((H & 1) || (W & 1)) return MH_ERR_ARG;
-  hipLaunchKernelGGL(relu_pool_bwd_kernel, dim3(cv_grid((long)B * (H / 2) * (W / 2) * C)), dim3(CV_NT), 0, stream, dp,
-                     (const bf16_t*)y, ldy, (bf16_t*)dy, lddy, B, H, W, C);
+  const dim3 grid(cv_grid((long)B * (H / 2) * (W / 2) * C)), block(CV_NT);
+  if (y_is_f32)
+    hipLaunchKernelGGL(relu_pool_bwd_kernel<float>, grid, block, 0, stream, dp, (const float*)y, ldy, (bf16_t*)dy, lddy, B,
+                       H, W, C);
+  else
+    hipLaunchKernelGGL(relu_pool_bwd_kernel<bf16_t>, grid, block, 0, stream, dp, (const bf16_t*)y, ldy, (bf16_t*)dy, lddy,
+                       B, H, W, C);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

@@ -381,3 +381,77 @@ extern "C" int mh_scale_f32(float* x, float a, long n, hipStream_t stream) {
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
+
+// ---- gather rows f32 -> f32 --------------------------------------------------------------------
+__global__ void gather_rows_f32_kernel(const float* __restrict__ src, long lds, const int* __restrict__ rows,
+                                       float* __restrict__ dst, long n, int D) {
+  const int per_row = D >> 2;
+  const long total = n * per_row;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long i = it / per_row;
+    const int c = (int)(it - i * per_row) * 4;
+    *reinterpret_cast<float4_t*>(dst + i * D + c) = *reinterpret_cast<const float4_t*>(src + (long)rows[i] * lds + c);
+  }
+}
+extern "C" int mh_gather_rows_f32(const float* src, long lds, const int* rows, float* dst, long n, int D,
+                                  hipStream_t stream) {
+  if (n <= 0) return MH_OK;
+  if (D % 4 || lds % 4) return MH_ERR_ARG;
+  hipLaunchKernelGGL(gather_rows_f32_kernel, dim3(ew_grid(n * (D / 4))), dim3(EW_NT), 0, stream, src, lds, rows, dst,
+                     n, D);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// ---- batched 2-D copy of bf16 (KV-cache append / slicing); cols % 8 == 0 --------------------------
+__global__ void copy3d_bf16_kernel(const bf16_t* __restrict__ src, long sb, long lds, bf16_t* __restrict__ dst,
+                                   long db, long ldd, int nb, long rows, int cols8) {
+  const long per_b = rows * cols8;
+  const long total = per_b * nb;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long b = it / per_b;
+    const long rem = it - b * per_b;
+    const long r = rem / cols8;
+    const int c = (int)(rem - r * cols8) * 8;
+    *reinterpret_cast<short8_t*>(dst + b * db + r * ldd + c) =
+        *reinterpret_cast<const short8_t*>(src + b * sb + r * lds + c);
+  }
+}
+extern "C" int mh_copy3d_bf16(const void* src, long src_bstride, long lds, void* dst, long dst_bstride, long ldd,
+                              int nb, long rows, int cols, hipStream_t stream) {
+  if (rows <= 0 || cols <= 0 || nb <= 0) return MH_OK;
+  if (cols % 8 || lds % 8 || ldd % 8 || src_bstride % 8 || dst_bstride % 8) return MH_ERR_ARG;
+  hipLaunchKernelGGL(copy3d_bf16_kernel, dim3(ew_grid(nb * rows * (cols / 8))), dim3(EW_NT), 0, stream,
+                     (const bf16_t*)src, src_bstride, lds, (bf16_t*)dst, dst_bstride, ldd, nb, rows, cols / 8);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// ---- K14 patchify: NCHW f32 image -> [B*np, Kpad] bf16 rows in conv-weight order (c, iy, ix) --------
+// reference eva_vit.py:196-204 (Conv2d kernel = stride = patch) expressed as a GEMM operand.
+__global__ void patchify_kernel(const float* __restrict__ img, bf16_t* __restrict__ out, int B, int C, int H, int W,
+                                int P, int K, int Kpad) {
+  const int gw = W / P, gh = H / P;
+  const long total = (long)B * gh * gw * Kpad;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const int k = (int)(it % Kpad);
+    const long m = it / Kpad;
+    float v = 0.f;
+    if (k < K) {
+      const int px = (int)(m % gw), py = (int)((m / gw) % gh), b = (int)(m / ((long)gw * gh));
+      const int c = k / (P * P), r = k - c * P * P, iy = r / P, ix = r - iy * P;
+      v = img[(((long)b * C + c) * H + py * P + iy) * W + px * P + ix];
+    }
+    out[it] = f2bf(v);
+  }
+}
+extern "C" int mh_patchify_nchw(const float* img, void* out, int B, int C, int H, int W, int P, int Kpad,
+                                hipStream_t stream) {
+  const int K = C * P * P;
+  if (H % P || W % P || Kpad < K) return MH_ERR_ARG;
+  const long total = (long)B * (H / P) * (W / P) * Kpad;
+  hipLaunchKernelGGL(patchify_kernel, dim3(ew_grid(total)), dim3(EW_NT), 0, stream, img, (bf16_t*)out, B, C, H, W, P, K,
+                     Kpad);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}

@@ -31,9 +31,10 @@ __device__ __forceinline__ int swz_off(int row, int chunk) { return row * (BK * 
 
 template <bool GLDS>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                         void* __restrict__ Cv, const float* __restrict__ bias,
+                                                         void* Cv, const float* __restrict__ bias,
                                                          const float* res, int M, int N, int K, int lda, int ldb,
-                                                         int ldc, int ldr, int flags, float alpha, int tiles_m) {
+                                                         int ldc, int ldr, int flags, float alpha, int tiles_m,
+                                                         int kt_per_split, long split_stride) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | B 16K]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -69,13 +70,17 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
-  const int nt = K / BK;
+  // split-K: blockIdx.y owns K tiles [kt0, kt0+nt) and writes its fp32 partial slab at Cv + y*split_stride
+  const int nt_all = K / BK;
+  const int kt0 = blockIdx.y * kt_per_split;
+  const int nt = (nt_all - kt0) < kt_per_split ? (nt_all - kt0) : kt_per_split;
+  if (gridDim.y > 1) Cv = reinterpret_cast<float*>(Cv) + blockIdx.y * split_stride;
   short8_t ra_[4], rb_[4];
 
   auto issue = [&](int t, int buf) {
     char* sA = smem + buf * 2 * STAGE_BYTES;
     char* sB = sA + STAGE_BYTES;
-    const int k0 = t * BK;
+    const int k0 = (kt0 + t) * BK;
     if (GLDS) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
@@ -205,11 +210,49 @@ extern "C" int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   }
   if (flags & MH_GEMM_REGSTAGE) {
     hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)B, C, bias,
-                       residual, M, N, K, lda, ldb, ldc, ldr, flags, alpha, tiles_m);
+                       residual, M, N, K, lda, ldb, ldc, ldr, flags, alpha, tiles_m, K / BK, 0L);
   } else {
     hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)B, C, bias,
-                       residual, M, N, K, lda, ldb, ldc, ldr, flags, alpha, tiles_m);
+                       residual, M, N, K, lda, ldb, ldc, ldr, flags, alpha, tiles_m, K / BK, 0L);
   }
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// ---- split-K variant for skinny outputs with a long reduction (wgrad of the conv stem, M,N small, K huge) ----
+// partial slabs ws[splits][M][N] fp32, then a fixed-order reduction -> deterministic.
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int M, int N, int ldc,
+                                     int splits) {
+  const long total = (long)M * N;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int k = 0; k < splits; ++k) s += ws[(long)k * total + i];
+    out[(i / N) * ldc + (i % N)] = s;
+  }
+}
+
+extern "C" long mh_gemm_splitk_ws_floats(int M, int N, int splits) { return (long)M * N * splits; }
+
+extern "C" int mh_gemm_bf16_nt_splitk(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N,
+                                      int K, int splits, float* ws, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return MH_OK;
+  if (K <= 0 || (K % BK) != 0 || (lda % 8) != 0 || (ldb % 8) != 0 || (N % 4) != 0 || splits < 1) return MH_ERR_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)ws & 15)) return MH_ERR_ARG;
+  const int nt = K / BK;
+  if (splits > nt) splits = nt;
+  const int tps = (nt + splits - 1) / splits;
+  splits = (nt + tps - 1) / tps;
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
+  const dim3 grid(tiles_m * tiles_n, splits), block(256);
+  const size_t shmem = 4 * STAGE_BYTES;
+  (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+  hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)B, (void*)ws,
+                     (const float*)nullptr, (const float*)nullptr, M, N, K, lda, ldb, N, 0, MH_GEMM_OUT_F32, 1.0f, tiles_m,
+                     tps, (long)M * N);
+  MH_CHECK_LAUNCH();
+  long g = ((long)M * N + 255) / 256;
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, stream, ws, C, M, N, ldc, splits);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

@@ -35,19 +35,20 @@ __global__ void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
 }
 
 // step is 1-based.  grad_scale multiplies the gradient first (e.g. 1/world after a sum all-reduce).
-extern "C" int mh_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, float lr,
-                             float beta1, float beta2, float eps, float weight_decay, int step, float grad_scale,
+extern "C" int mh_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, double lr,
+                             double beta1, double beta2, double eps, double weight_decay, int step, double grad_scale,
                              hipStream_t stream) {
   if (n <= 0) return MH_OK;
   if (n % 4 || step < 1) return MH_ERR_ARG;
   // bias corrections and (1-beta) in double on the host, like torch.optim.AdamW
-  const float bc1 = (float)(1.0 - pow((double)beta1, (double)step));
-  const float bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
-  const float omb1 = (float)(1.0 - (double)beta1), omb2 = (float)(1.0 - (double)beta2);
+  const float bc1 = (float)(1.0 - pow(beta1, (double)step));
+  const float bc2s = (float)sqrt(1.0 - pow(beta2, (double)step));
+  const float omb1 = (float)(1.0 - beta1), omb2 = (float)(1.0 - beta2);
   long grid = (n / 4 + 255) / 256;
   if (grid > 256 * 16) grid = 256 * 16;
-  hipLaunchKernelGGL(adamw_kernel, dim3((int)grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow_bf16, n / 4, lr,
-                     beta1, beta2, omb1, omb2, eps, weight_decay, bc1, bc2s, grad_scale);
+  hipLaunchKernelGGL(adamw_kernel, dim3((int)grid), dim3(256), 0, stream, p, g, m, v, (bf16_t*)shadow_bf16, n / 4,
+                     (float)lr, (float)beta1, (float)beta2, omb1, omb2, (float)eps, (float)weight_decay, bc1, bc2s,
+                     (float)grad_scale);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

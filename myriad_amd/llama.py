@@ -1,0 +1,224 @@
+"""Vicuna / LLaMA decoder on the HIP kernels: training forward + dgrad-only backward, and KV-cache decode.
+
+Mirrors the reference's `LlamaForCausalLM` (minigpt4/models/modeling_llama.py:629-716), `LlamaModel.forward`
+(:466-596), `LlamaDecoderLayer.forward` (:247-299), `LlamaAttention.forward` (:168-231) and
+`clamp_CE_loss` (:718-728) for the call patterns Myriad uses (inputs_embeds + attention_mask + labels; greedy
+decode from inputs_embeds).  Weights are frozen (myriad.py:202-205), so the backward is dgrad only.
+
+MI355X layout decisions (288 GB HBM): every frozen weight is kept twice in bf16 -- W [out,in] for forward and
+W^T [in,out] for dgrad -- so forward and backward both run the single K-contiguous MFMA GEMM; q/k/v and
+gate/up are fused into one GEMM each; the residual stream and all norm statistics are fp32; the lm_head and
+the clamp-CE loss run only on label-bearing rows (the other rows have zero gradient and no loss term).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def _bf(t: torch.Tensor, dev) -> torch.Tensor:
+    return t.detach().to(device=dev, dtype=BF16).contiguous()
+
+
+def _f32(t: torch.Tensor, dev) -> torch.Tensor:
+    return t.detach().to(device=dev, dtype=F32).contiguous()
+
+
+class LlamaHIP:
+    def __init__(self, sd: Dict[str, torch.Tensor], n_heads: int, device, eps: float = 1e-6,
+                 prefix: str = "llama_model.", max_pos: int = 2048, need_backward: bool = True):
+        self.dev = torch.device(device)
+        self.H = n_heads
+        self.eps = eps
+        p = prefix + "model."
+        self.embed = _bf(sd[p + "embed_tokens.weight"], self.dev)
+        self.V, self.D = self.embed.shape
+        self.hd = self.D // n_heads
+        self.layers: List[dict] = []
+        i = 0
+        while (p + f"layers.{i}.input_layernorm.weight") in sd:
+            lp = p + f"layers.{i}."
+            wq, wk, wv = (sd[lp + f"self_attn.{n}_proj.weight"] for n in "qkv")
+            wqkv = _bf(torch.cat([wq, wk, wv], 0), self.dev)
+            wo = _bf(sd[lp + "self_attn.o_proj.weight"], self.dev)
+            # intermediate size padded to a multiple of 64 (GEMM K granule); zero rows/cols are exact no-ops
+            wg, wu, wdn = sd[lp + "mlp.gate_proj.weight"], sd[lp + "mlp.up_proj.weight"], sd[lp + "mlp.down_proj.weight"]
+            I0 = wg.shape[0]
+            Ip = ops.round_up(I0, 64)
+            if Ip != I0:
+                z = torch.zeros(Ip - I0, wg.shape[1], dtype=wg.dtype, device=wg.device)
+                wg, wu = torch.cat([wg, z], 0), torch.cat([wu, z], 0)
+                wdn = torch.cat([wdn, torch.zeros(wdn.shape[0], Ip - I0, dtype=wdn.dtype, device=wdn.device)], 1)
+            wgu = _bf(torch.cat([wg, wu], 0), self.dev)
+            wd = _bf(wdn, self.dev)
+            L = dict(wqkv=wqkv, wo=wo, wgu=wgu, wd=wd,
+                     ln1=_f32(sd[lp + "input_layernorm.weight"], self.dev),
+                     ln2=_f32(sd[lp + "post_attention_layernorm.weight"], self.dev))
+            if need_backward:
+                L.update(wqkvT=wqkv.t().contiguous(), woT=wo.t().contiguous(), wguT=wgu.t().contiguous(),
+                         wdT=wd.t().contiguous())
+            self.layers.append(L)
+            i += 1
+        self.I = self.layers[0]["wd"].shape[1]
+        self.norm = _f32(sd[p + "norm.weight"], self.dev)
+        self.lm_head = _bf(sd[prefix + "lm_head.weight"], self.dev)
+        self.Vpad = ops.round_up(self.V, 64)
+        if need_backward:
+            lmT = torch.zeros((self.D, self.Vpad), dtype=BF16, device=self.dev)
+            lmT[:, :self.V] = self.lm_head.t()
+            self.lm_headT = lmT
+        inv_freq = 1.0 / (10000.0 ** (torch.arange(0, self.hd, 2).float() / self.hd))
+        fr = torch.einsum("i,j->ij", torch.arange(max_pos).float(), inv_freq)
+        self.cos = fr.cos().contiguous().to(self.dev)
+        self.sin = fr.sin().contiguous().to(self.dev)
+        self._saved = None
+
+    # ------------------------------------------------------------------ training forward
+    def forward_loss(self, x: torch.Tensor, attention_mask: torch.Tensor, labels: torch.Tensor,
+                     save_for_backward: bool = True) -> torch.Tensor:
+        """x: [B,S,D] f32 inputs_embeds (device); attention_mask/labels: [B,S] CPU or device int64.
+        Returns the 0-d f32 loss tensor (device).  Stores what `backward()` needs."""
+        B, S, D = x.shape
+        M = B * S
+        H, hd, W = self.H, self.hd, self.D
+        am = attention_mask.to("cpu")
+        kv_len_host = am.sum(-1).to(torch.int32)
+        if not bool((am == (torch.arange(S)[None] < kv_len_host[:, None])).all()):
+            raise ValueError("attention_mask must be right-padded (ones then zeros), as the reference builds it")
+        kv_len = kv_len_host.to(self.dev)
+        pos = torch.arange(S, dtype=torch.int32).repeat(B).to(self.dev)  # position_ids = arange (modeling_llama.py:519-523)
+        scale = 1.0 / math.sqrt(hd)
+        h = x.reshape(M, D)
+        saved = []
+        for L in self.layers:
+            xn = ops.rmsnorm_fwd(h, L["ln1"], self.eps)
+            qkv = ops.gemm(xn, L["wqkv"])                                   # [M, 3W] bf16
+            ops.rope_(qkv, 0, 2 * H, hd, pos, self.cos, self.sin, 1.0)      # q and k heads
+            q3 = qkv.view(B, S, 3 * W)
+            o, lse = ops.attn_fwd(q3[:, :, :W], q3[:, :, W:2 * W], q3[:, :, 2 * W:], H, hd, scale, causal=True,
+                                  kv_len=kv_len)
+            h2 = ops.gemm(o.view(M, W), L["wo"], residual=h, out_dtype=F32)
+            xn2 = ops.rmsnorm_fwd(h2, L["ln2"], self.eps)
+            gu = ops.gemm(xn2, L["wgu"])                                    # [M, 2I]
+            act = ops.silu_mul_fwd(gu)
+            h3 = ops.gemm(act, L["wd"], residual=h2, out_dtype=F32)
+            if save_for_backward:
+                saved.append((h, qkv, o, lse, h2, gu))
+            h = h3
+        # loss on label-bearing rows only: row (b,s) predicts labels[b,s+1]
+        lab = labels.to("cpu")
+        shift = lab[:, 1:]
+        bi, si = torch.nonzero(shift != -100, as_tuple=True)
+        rows = (bi * S + si).to(torch.int32).to(self.dev)
+        tgt = shift[bi, si].to(self.dev)
+        n_valid = int(rows.numel())
+        if n_valid == 0:
+            raise ValueError("no valid labels")
+        hr = ops.gather_rows_f32(h, rows)
+        hn = ops.rmsnorm_fwd(hr, self.norm, self.eps)
+        logits = ops.gemm(hn, self.lm_head, out_dtype=F32)                  # [R, V] f32
+        row_loss, dlogits = ops.clamp_ce(logits, tgt, 1.0 / n_valid, want_grad=save_for_backward, ldd=self.Vpad)
+        loss = ops.sum_f32(row_loss, 1.0 / n_valid)
+        if save_for_backward:
+            self._saved = dict(layers=saved, rows=rows, hr=hr, dlogits=dlogits, B=B, S=S, kv_len=kv_len, pos=pos,
+                               scale=scale)
+        return loss.view(())
+
+    # ------------------------------------------------------------------ dgrad-only backward
+    def backward(self, loss_scale: float = 1.0) -> torch.Tensor:
+        """Returns d(loss)/d(inputs_embeds) as [B,S,D] f32."""
+        sv = self._saved
+        if sv is None:
+            raise RuntimeError("backward() called without a saved forward")
+        B, S = sv["B"], sv["S"]
+        M, D, W, H, hd = B * S, self.D, self.D, self.H, self.hd
+        dlog = sv["dlogits"]
+        if loss_scale != 1.0:
+            raise NotImplementedError("loss scaling is unnecessary in bf16; pass 1.0")
+        dhn = ops.gemm(dlog, self.lm_headT, out_dtype=F32)                  # [R, D]
+        dhr, _ = ops.rmsnorm_bwd(dhn, sv["hr"], self.norm, self.eps)
+        dh = torch.zeros((M, D), dtype=F32, device=self.dev)
+        ops.scatter_rows(dhr, sv["rows"], dh)
+        dh_b = ops.to_bf16(dh)
+        for L, (h_in, qkv, o, lse, h2, gu) in zip(reversed(self.layers), reversed(sv["layers"])):
+            dact = ops.gemm(dh_b, L["wdT"])                                 # [M, I] bf16
+            dgu = ops.silu_mul_bwd(dact, gu)
+            dxn2 = ops.gemm(dgu, L["wguT"], out_dtype=F32)                  # [M, D]
+            dh2, dh2_b = ops.rmsnorm_bwd(dxn2, h2, L["ln2"], self.eps, dres=dh, want_bf16=True)
+            do = ops.gemm(dh2_b, L["woT"])                                  # [M, W] bf16
+            q3 = qkv.view(B, S, 3 * W)
+            dqkv = torch.empty_like(qkv)
+            d3 = dqkv.view(B, S, 3 * W)
+            ops.attn_bwd(q3[:, :, :W], q3[:, :, W:2 * W], q3[:, :, 2 * W:], o, do.view(B, S, W), lse, H, hd,
+                         sv["scale"], causal=True, kv_len=sv["kv_len"], dq=d3[:, :, :W], dk=d3[:, :, W:2 * W],
+                         dv=d3[:, :, 2 * W:])
+            ops.rope_(dqkv, 0, 2 * H, hd, sv["pos"], self.cos, self.sin, -1.0)
+            dxn = ops.gemm(dqkv, L["wqkvT"], out_dtype=F32)
+            dh, dh_b = ops.rmsnorm_bwd(dxn, h_in, L["ln1"], self.eps, dres=dh2, want_bf16=True)
+        self._saved = None
+        return dh.view(B, S, D)
+
+    # ------------------------------------------------------------------ generation
+    @torch.no_grad()
+    def greedy_generate(self, inputs_embeds: torch.Tensor, max_new_tokens: int = 90,
+                        stop_ids=((835,), (2277, 29937)), eos_id: int = 2, min_length: int = 1,
+                        return_margins: bool = False):
+        """Greedy decode from [B,S0,D] f32 embeddings with a KV cache (prefill + 1-token steps).  Same contract
+        as the oracle's greedy_generate: stop when ROW 0 ends with a stop sequence (conversation.py:102-107),
+        EOS banned while fewer than `min_length` tokens were generated, finished rows padded with EOS."""
+        B, S0, D = inputs_embeds.shape
+        H, hd, W = self.H, self.hd, self.D
+        T = S0 + max_new_tokens
+        scale = 1.0 / math.sqrt(hd)
+        caches = [torch.empty((B, T, 2 * W), dtype=BF16, device=self.dev) for _ in self.layers]
+        out_ids, margins = [], []
+        unfinished = torch.ones(B, dtype=torch.long)
+        x = inputs_embeds.reshape(B * S0, D).contiguous()
+        S, past = S0, 0
+        for step in range(max_new_tokens):
+            M = B * S
+            pos = (torch.arange(S, dtype=torch.int32) + past).repeat(B).to(self.dev)
+            h = x
+            for L, cache in zip(self.layers, caches):
+                xn = ops.rmsnorm_fwd(h, L["ln1"], self.eps)
+                qkv = ops.gemm(xn, L["wqkv"])
+                ops.rope_(qkv, 0, 2 * H, hd, pos, self.cos, self.sin, 1.0)
+                q3 = qkv.view(B, S, 3 * W)
+                ops.copy3d_bf16(q3[:, :, W:], cache[:, past:past + S])       # append k|v
+                kc = cache[:, :past + S]
+                o, _ = ops.attn_fwd(q3[:, :, :W], kc[:, :, :W], kc[:, :, W:], H, hd, scale, causal=True, need_lse=False)
+                h2 = ops.gemm(o.view(M, W), L["wo"], residual=h, out_dtype=F32)
+                xn2 = ops.rmsnorm_fwd(h2, L["ln2"], self.eps)
+                act = ops.silu_mul_fwd(ops.gemm(xn2, L["wgu"]))
+                h = ops.gemm(act, L["wd"], residual=h2, out_dtype=F32)
+            last = h.view(B, S, D)[:, -1].contiguous()
+            logits = ops.gemm(ops.rmsnorm_fwd(last, self.norm, self.eps), self.lm_head, out_dtype=F32)
+            ban = eos_id if step < min_length else -1
+            nxt_d, mar = ops.argmax_rows(logits, ban_id=ban, want_margin=True)
+            nxt = nxt_d.cpu()
+            margins.append(mar.cpu())
+            nxt = nxt * unfinished + eos_id * (1 - unfinished)
+            unfinished = unfinished * (nxt != eos_id).long()
+            out_ids.append(nxt)
+            row0 = [int(t[0]) for t in out_ids]
+            if any(len(row0) >= len(s) and row0[-len(s):] == list(s) for s in stop_ids):
+                break
+            if int(unfinished.max()) == 0:
+                break
+            past += S
+            S = 1
+            x = torch.empty((B, D), dtype=F32, device=self.dev)
+            ops.embed_gather(self.embed, nxt.to(self.dev), x)
+        ids = torch.stack(out_ids, 1)
+        if return_margins:
+            return ids, torch.stack(margins, 1)
+        return ids
+
+    def embed_tokens_into(self, ids: torch.Tensor, out2d: torch.Tensor, dst_rows: Optional[torch.Tensor] = None):
+        ops.embed_gather(self.embed, ids, out2d, dst_rows)

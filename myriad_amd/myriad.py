@@ -1,0 +1,432 @@
+"""`Myriad` / `MiniGPT4` model classes on the MI355X HIP path -- the drop-in boundary.
+
+Mirror of the reference's registered model classes (minigpt4/models/myriad.py:62-517, mini_gpt4.py:14-307):
+`from_config(cfg)`, `forward(samples) -> {"loss"}`, `generate(samples, **kw) -> {"token_ids", "ve_anomaly_maps"}`,
+`named_parameters()` / `requires_grad`, `state_dict()` / `load_state_dict(strict=False)` with the reference's key
+names, `.device`, `.train()/.eval()`.  The forward follows `Myriad.forward` (myriad.py:377-431) ->
+`encode_img` (:241-272) -> `prompt_wrap` (:354-375) -> label/mask assembly (:395-421) -> LLaMA loss; every tensor
+op runs in libmyriad_hip.so.  The backward is explicit (frozen ViT/Q-Former/LLaMA => dgrad only) and
+is also reachable through `loss.backward()` via a thin autograd bridge so the reference's step loop
+(tasks/base_task.py:236-271) works unchanged.
+
+Out of scope here: the ImageBind vision expert.  Its outputs are inputs to this model:
+`samples["anomaly_maps"]` / `samples["oneshot_anomaly_maps"]` [B,1,224,224] in [0,1].
+"""
+from __future__ import annotations
+
+import random
+from collections import OrderedDict
+from typing import Dict, List, Optional, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .eva_vit import EvaViTHIP
+from .llama import LlamaHIP
+from .networks import LoraAdaptor, VENet, from_reference_layout, to_reference_layout, ve_param_specs
+from .qformer import QFormerHIP
+from .registry import registry
+
+BF16, F32 = torch.bfloat16, torch.float32
+
+
+def uses_weight_decay(name: str, ndim: int) -> bool:
+    """Parameter grouping of `RunnerBase.optimizer` (reference runners/runner_base.py:115-118)."""
+    return not (ndim < 2 or "bias" in name or "ln" in name or "bn" in name)
+
+
+class ParamStore:
+    """All trainable parameters in ONE flat fp32 buffer (+ grad, Adam m, v): a single RCCL all-reduce and two
+    fused AdamW launches per step.  Layout: [weight-decay group | no-decay group], segments 16-byte aligned."""
+
+    def __init__(self, specs: List[Tuple[str, Tuple[int, ...], Tuple[int, ...]]], device):
+        self.dev = torch.device(device)
+        wd = [s for s in specs if uses_weight_decay(s[0], len(s[2]))]
+        nwd = [s for s in specs if not uses_weight_decay(s[0], len(s[2]))]
+        self.specs = wd + nwd
+        self.offsets: Dict[str, Tuple[int, int]] = {}
+        off = 0
+        for i, (name, ishape, _) in enumerate(self.specs):
+            if i == len(wd):
+                self.n_wd = off
+            n = 1
+            for s in ishape:
+                n *= s
+            self.offsets[name] = (off, n)
+            off += ops.round_up(n, 4)
+        if not nwd:
+            self.n_wd = off
+        self.total = off
+        self.flat_p = torch.zeros(off, dtype=F32, device=self.dev)
+        self.flat_g = torch.zeros(off, dtype=F32, device=self.dev)
+        self.flat_m = torch.zeros(off, dtype=F32, device=self.dev)
+        self.flat_v = torch.zeros(off, dtype=F32, device=self.dev)
+        self.p, self.g = {}, {}
+        self.ref_shape = {}
+        for name, ishape, rshape in self.specs:
+            o, n = self.offsets[name]
+            self.p[name] = self.flat_p[o:o + n].view(ishape)
+            self.g[name] = self.flat_g[o:o + n].view(ishape)
+            self.ref_shape[name] = rshape
+        self.step = 0
+
+    def n_params(self) -> int:
+        return sum(n for _, n in self.offsets.values())
+
+    def adamw_step(self, lr: float, weight_decay: float = 0.05, beta2: float = 0.999, grad_scale: float = 1.0):
+        """torch.optim.AdamW semantics (runner_base.py:132-137), fused, on the flat buffers."""
+        self.step += 1
+        a = self.n_wd
+        if a > 0:
+            ops.adamw_step(self.flat_p[:a], self.flat_g[:a], self.flat_m[:a], self.flat_v[:a], lr, weight_decay,
+                           self.step, beta2=beta2, grad_scale=grad_scale)
+        if self.total > a:
+            ops.adamw_step(self.flat_p[a:], self.flat_g[a:], self.flat_m[a:], self.flat_v[a:], lr, 0.0, self.step,
+                           beta2=beta2, grad_scale=grad_scale)
+
+
+class _LossBridge(torch.autograd.Function):
+    """Lets `loss.backward()` (reference base_task.py:256-259) drive the explicit HIP backward: gradients are
+    written straight into the parameters' .grad views of the flat buffer (no extra copy)."""
+
+    @staticmethod
+    def forward(ctx, anchor, model, loss):
+        ctx.model = model
+        return loss.detach().clone()
+
+    @staticmethod
+    def backward(ctx, gout):
+        ctx.model.backward(float(gout))
+        return None, None, None
+
+
+class MyriadHIP(nn.Module):
+    arch = "myriad"
+
+    def __init__(self, weights, cfg: Optional[dict] = None, device="cuda:0"):
+        super().__init__()
+        cfg = dict(cfg or {})
+        self.cfg = cfg
+        self._dev = torch.device(device)
+        self.max_txt_len = cfg.get("max_txt_len", 160)
+        self.end_sym = cfg.get("end_sym", "###")
+        self.k_shot = cfg.get("k_shot", 0)
+        self.fixed_stage = cfg.get("fixed_stage", None)        # None => random.choice like the reference
+        self.fixed_taskstage = cfg.get("fixed_taskstage", None)
+        self.bos_id, self.pad_id = cfg.get("bos_token_id", 1), cfg.get("pad_token_id", 2)
+        self.llama_tokenizer = cfg.get("tokenizer", None)
+        self.prompt_list = cfg.get("prompt_list", [])
+        need_bwd = cfg.get("need_backward", True)
+        self.visual_encoder = EvaViTHIP(weights, cfg.get("vit_heads", 16), self._dev)
+        self.qformer = QFormerHIP(weights, cfg.get("qf_heads", 12), self._dev,
+                                  need_backward=need_bwd and self.arch == "myriad")
+        self.llama = LlamaHIP(weights, cfg.get("llm_heads", 32), self._dev, need_backward=need_bwd)
+        self.ln_w = weights["ln_vision.weight"].to(self._dev, F32).contiguous()
+        self.ln_b = weights["ln_vision.bias"].to(self._dev, F32).contiguous()
+        self.query_tokens_f32 = weights["query_tokens"].to(self._dev, F32).contiguous()      # frozen (myriad.py:165)
+        self.proj_w = weights["llama_proj.weight"].to(self._dev, BF16).contiguous()
+        self.proj_b = weights["llama_proj.bias"].to(self._dev, F32).contiguous()
+        self.proj_wT = self.proj_w.t().contiguous()
+        self.Dv, self.Dq, self.Dl = self.visual_encoder.D, self.qformer.D, self.llama.D
+        self.nq0 = self.query_tokens_f32.shape[1]
+        # ---- trainables
+        specs = []
+        if self.arch == "myriad":
+            specs.append(("expert_adaptor.conv1.weight", (4, self.Dv), (4, self.Dv)))
+            specs.append(("expert_adaptor.conv2.weight", (self.Dv, 4), (self.Dv, 4)))
+            specs += ve_param_specs("VETokenizer.", self.Dl, 5)
+            specs.append(("VETokenizer.base_prompts", (9, self.Dl), (9, self.Dl)))
+            specs += ve_param_specs("VEInstructor.", self.Dq, 1)
+        else:
+            specs.append(("llama_proj.weight", (self.Dl, self.Dq), (self.Dl, self.Dq)))
+            specs.append(("llama_proj.bias", (self.Dl,), (self.Dl,)))
+        self.store = ParamStore(specs, self._dev)
+        self._params = OrderedDict()
+        for name, ishape, rshape in self.store.specs:
+            self.store.p[name].copy_(from_reference_layout(weights[name].to(self._dev, F32), ishape))
+            prm = nn.Parameter(self.store.p[name], requires_grad=True)
+            prm.grad = self.store.g[name]
+            self._params[name] = prm
+            self._register_dotted(name, prm)
+        if self.arch == "myriad":
+            self.adaptor = LoraAdaptor(self.store.p, self.store.g)
+            self.ve_tok = VENet("VETokenizer.", 5, self.Dl, self.store.p, self.store.g, self._dev)
+            self.ve_ins = VENet("VEInstructor.", 1, self.Dq, self.store.p, self.store.g, self._dev)
+        self._anchor = torch.zeros((), device=self._dev, requires_grad=True)
+        self._ctx = None
+
+    # ------------------------------------------------------------------ nn.Module plumbing
+    def _register_dotted(self, name: str, prm: nn.Parameter):
+        mod = self
+        parts = name.split(".")
+        for part in parts[:-1]:
+            if not hasattr(mod, part) or not isinstance(getattr(mod, part), nn.Module):
+                setattr(mod, part, nn.Module())
+            mod = getattr(mod, part)
+        mod.register_parameter(parts[-1], prm)
+
+    @property
+    def device(self):
+        return self._dev
+
+    def to(self, *args, **kwargs):   # the model is built in place on its device
+        dev = args[0] if args else kwargs.get("device", self._dev)
+        if isinstance(dev, (str, torch.device)) and torch.device(dev).type != self._dev.type:
+            raise RuntimeError(f"{type(self).__name__} lives on {self._dev}; build it there (no CPU path exists)")
+        return self
+
+    def before_evaluation(self, **kwargs):   # base_model.py:102-103
+        pass
+
+    def state_dict(self, *a, **k):
+        """Trainable parameters under the reference's key names and tensor layouts (runner_base.py:598-605 keeps
+        exactly the requires_grad parameters)."""
+        out = OrderedDict()
+        for name, _, rshape in self.store.specs:
+            out[name] = to_reference_layout(self.store.p[name].detach(), rshape).cpu()
+        return out
+
+    def load_state_dict(self, sd, strict: bool = False):
+        missing = []
+        for name, ishape, _ in self.store.specs:
+            if name in sd:
+                self.store.p[name].copy_(from_reference_layout(sd[name].to(self._dev, F32), ishape))
+            else:
+                missing.append(name)
+        if strict and missing:
+            raise KeyError(missing)
+        return missing
+
+    @classmethod
+    def from_config(cls, cfg):
+        """`Myriad.from_config` (myriad.py:456-517).  cfg['weights'] is a mapping keyed by the reference's
+        state_dict names (a loaded checkpoint dict or myriad_amd.synthetic.SyntheticWeights)."""
+        get = cfg.get if hasattr(cfg, "get") else (lambda k, d=None: getattr(cfg, k, d))
+        weights = get("weights")
+        if weights is None:
+            raise ValueError("cfg['weights'] is required (checkpoint state dict or SyntheticWeights)")
+        keys = ("max_txt_len", "end_sym", "k_shot", "fixed_stage", "fixed_taskstage", "tokenizer", "prompt_list",
+                "vit_heads", "qf_heads", "llm_heads", "need_backward", "bos_token_id", "pad_token_id")
+        sub = {k: get(k) for k in keys if get(k) is not None}
+        model = cls(weights, sub, device=get("device", "cuda:0"))
+        ckpt = get("ckpt", "")
+        if ckpt:
+            model.load_state_dict(torch.load(ckpt, map_location="cpu")["model"], strict=False)
+        return model
+
+    # ------------------------------------------------------------------ hot path
+    def _tokenize(self, samples, B, stage, training):
+        """prompt_wrap tokenisation (myriad.py:358-366) + targets (:395-405); integer ids may be supplied directly."""
+        if "before_ids" in samples:
+            before, after = samples["before_ids"], samples["after_ids"]
+            tgt, tmask = samples.get("target_ids"), samples.get("target_mask")
+            return before, after, tgt, tmask
+        tok = self.llama_tokenizer
+        if tok is None:
+            raise RuntimeError("no tokenizer: pass integer ids (before_ids/after_ids/target_ids/target_mask) in samples")
+        key = {0: "question", 1: "question2", 2: "question3"}[stage] if self.arch == "myriad" else "question"
+        qs = samples[key]
+        if training and "aug_image" in samples:
+            qs = list(qs) + list(qs)
+        prompts = ["###Human: " + q + " ###Assistant: " for q in qs]
+        bs, as_ = [], []
+        for p in prompts:
+            pb, pa = p.split("<ImageHere>")
+            bs.append(tok(pb, return_tensors="pt", add_special_tokens=False).input_ids[0])
+            as_.append(tok(pa, return_tensors="pt", add_special_tokens=False).input_ids[0])
+        before, after = torch.stack(bs), torch.stack(as_)     # torch.stack => equal lengths, like myriad.py:371
+        tgt = tmask = None
+        if training:
+            texts = list(samples["text_input"]) + list(samples.get("aug_text_input", []))
+            tok.padding_side = "right"
+            enc = tok([t + self.end_sym for t in texts], return_tensors="pt", padding="longest", truncation=True,
+                      max_length=self.max_txt_len, add_special_tokens=False)
+            tgt, tmask = enc.input_ids, enc.attention_mask
+        return before, after, tgt, tmask
+
+    def encode_img(self, image, maps, stage, save=True):
+        """`Myriad.encode_img` (myriad.py:241-272).  Returns img tokens [B, n_img, Dl] f32."""
+        B = image.shape[0]
+        x = self.visual_encoder.forward(image)                      # [B,257,Dv] f32, frozen
+        N = x.shape[1]
+        x2 = x.view(B * N, self.Dv)
+        y = self.adaptor.forward(x2, save) if self.arch == "myriad" else x2
+        enc_b, _ = ops.layernorm_fwd(y, self.ln_w, self.ln_b, 1e-5)   # ln_vision (blip2.py:119-125)
+        use_ins = self.arch == "myriad" and stage in (1, 2)
+        use_tok = self.arch == "myriad" and stage in (0, 1)
+        nq = self.nq0 + (49 if use_ins else 0)
+        q = torch.empty((B, nq, self.Dq), dtype=F32, device=self._dev)
+        ops.copy3d(self.query_tokens_f32.expand(B, -1, -1), q[:, :self.nq0])
+        if use_ins:
+            ops.copy3d(self.ve_ins.forward(maps, save), q[:, self.nq0:])
+        qo = self.qformer.forward(q, enc_b.view(B, N, self.Dv), save and self.arch == "myriad")
+        qo_b = ops.to_bf16(qo.view(B * nq, self.Dq))
+        if self.arch == "myriad":
+            pw, pb = self.proj_w, self.proj_b                         # frozen (myriad.py:218-219)
+        else:
+            pw, pb = ops.to_bf16(self.store.p["llama_proj.weight"]), self.store.p["llama_proj.bias"]
+        img = ops.gemm(qo_b, pw, bias=pb, out_dtype=F32)
+        parts = [img.view(B, nq, self.Dl)]
+        if use_tok:
+            parts.append(self.store.p["VETokenizer.base_prompts"].view(1, 9, self.Dl).expand(B, -1, -1))
+            parts.append(self.ve_tok.forward(maps, save))
+        if save:
+            self._ctx = dict(B=B, N=N, y=y, nq=nq, use_ins=use_ins, use_tok=use_tok, qo_b=qo_b)
+        return parts
+
+    def _assemble(self, parts, before, after, tgt, tmask):
+        """inputs_embeds = cat(bos, before, img, after, text) (myriad.py:370-371,413-419) + mask/labels (:395-421)."""
+        B = parts[0].shape[0]
+        nb, na = before.shape[1], after.shape[1]
+        n_img = sum(p.shape[1] for p in parts)
+        T = 0 if tgt is None else tgt.shape[1]
+        S = 1 + nb + n_img + na + T
+        emb = torch.empty((B, S, self.Dl), dtype=F32, device=self._dev)
+        col = 1 + nb
+        img_slices = []
+        for p in parts:
+            ops.copy3d(p, emb[:, col:col + p.shape[1]])
+            img_slices.append((col, p.shape[1]))
+            col += p.shape[1]
+        ids, rows = [], []
+        for b in range(B):
+            base = b * S
+            ids.append(torch.tensor([self.bos_id]))
+            rows.append(torch.tensor([base]))
+            ids.append(before[b]); rows.append(base + 1 + torch.arange(nb))
+            ids.append(after[b]); rows.append(base + 1 + nb + n_img + torch.arange(na))
+            if T:
+                ids.append(tgt[b]); rows.append(base + 1 + nb + n_img + na + torch.arange(T))
+        ids = torch.cat(ids).long().to(self._dev)
+        rows = torch.cat(rows).int().to(self._dev)
+        self.llama.embed_tokens_into(ids, emb.view(B * S, self.Dl), rows)
+        attn = labels = None
+        if T:
+            attn = torch.cat([torch.ones(B, 1 + nb + n_img + na, dtype=torch.long), tmask.long().cpu()], 1)
+            targets = tgt.cpu().masked_fill(tgt.cpu() == self.pad_id, -100)
+            labels = torch.cat([torch.full((B, 1 + nb + n_img + na), -100, dtype=torch.long), targets], 1)
+        return emb, attn, labels, img_slices
+
+    def _forward_impl(self, samples, need_grad: bool):
+        stage = self.fixed_stage if self.fixed_stage is not None else random.choice([0, 1, 2])   # myriad.py:378
+        if self.arch != "myriad":
+            stage = 0
+        image = samples["image"]
+        if "aug_image" in samples and self.training:
+            image = torch.cat([image, samples["aug_image"]])          # myriad.py:315-316
+        image = image.to(self._dev, F32)
+        maps = None
+        if self.arch == "myriad":
+            task = self.fixed_taskstage if self.fixed_taskstage is not None else random.choice([0, 1])  # :381
+            key = "anomaly_maps" if task == 0 else "oneshot_anomaly_maps"
+            if key not in samples:
+                raise KeyError(f"samples['{key}'] is required: the vision expert is an upstream producer "
+                               "(SURVEY 2.1 row 10)")
+            maps = samples[key].to(self._dev, F32)
+        before, after, tgt, tmask = self._tokenize(samples, image.shape[0], stage, True)
+        parts = self.encode_img(image, maps, stage, need_grad)
+        emb, attn, labels, img_slices = self._assemble(parts, before, after, tgt, tmask)
+        loss = self.llama.forward_loss(emb, attn, labels, save_for_backward=need_grad)
+        if need_grad:
+            self._ctx["img_slices"] = img_slices
+        return loss
+
+    def forward(self, samples):
+        """`Myriad.forward` (myriad.py:377-431).  Returns {"loss": 0-d tensor}; `loss.backward()` works."""
+        need_grad = torch.is_grad_enabled() and self.training and self.store.total > 0
+        with torch.no_grad():
+            loss = self._forward_impl(samples, need_grad)
+        if need_grad:
+            return {"loss": _LossBridge.apply(self._anchor, self, loss)}
+        return {"loss": loss}
+
+    def backward(self, gscale: float = 1.0):
+        """Explicit backward of the last forward: fills the flat gradient buffer (unused modules -> zeros,
+        the DDP find_unused_parameters semantics of runner_base.py:96-98)."""
+        c = self._ctx
+        if c is None:
+            raise RuntimeError("backward() without a training forward")
+        if gscale != 1.0:
+            raise NotImplementedError("bf16 path needs no loss scaling")
+        self.store.flat_g.zero_()
+        demb = self.llama.backward()                                  # [B,S,Dl] f32
+        B, nq = c["B"], c["nq"]
+        (c0, n0) = c["img_slices"][0]
+        dimg = torch.empty((B, nq, self.Dl), dtype=F32, device=self._dev)
+        ops.copy3d(demb[:, c0:c0 + n0], dimg)
+        dimg_b = ops.to_bf16(dimg.view(B * nq, self.Dl))
+        if self.arch != "myriad":
+            # MiniGPT-4 stage-2: llama_proj is the trainable piece (mini_gpt4.py:98-100): wgrad only
+            ops.gemm_auto_f32(ops.transpose_to_bf16(dimg_b, 64), ops.transpose_to_bf16(c["qo_b"], 64),
+                              self.store.g["llama_proj.weight"])
+            self.store.g["llama_proj.bias"].copy_(ops.colsum(dimg.view(B * nq, self.Dl)))
+            self._reattach_grads()
+            self._ctx = None
+            return
+        dqo = ops.gemm(dimg_b, self.proj_wT, out_dtype=F32).view(B, nq, self.Dq)
+        if c["use_tok"]:
+            (cb, _), (ct, _) = c["img_slices"][1], c["img_slices"][2]
+            dbase = torch.empty((B, 9, self.Dl), dtype=F32, device=self._dev)
+            ops.copy3d(demb[:, cb:cb + 9], dbase)
+            self.store.g["VETokenizer.base_prompts"].view(-1).copy_(ops.colsum(dbase.view(B, 9 * self.Dl)))
+            dtok = torch.empty((B, 9, self.Dl), dtype=F32, device=self._dev)
+            ops.copy3d(demb[:, ct:ct + 9], dtok)
+            self.ve_tok.backward(dtok)
+        dq, denc = self.qformer.backward(dqo)
+        if c["use_ins"]:
+            dins = torch.empty((B, 49, self.Dq), dtype=F32, device=self._dev)
+            ops.copy3d(dq[:, self.nq0:], dins)
+            self.ve_ins.backward(dins)
+        dy, _ = ops.layernorm_bwd(denc.view(B * c["N"], self.Dv), c["y"], self.ln_w, 1e-5)
+        self.adaptor.backward(dy)
+        self._reattach_grads()
+        self._ctx = None
+
+    def _reattach_grads(self):
+        # the reference loop calls optimizer.zero_grad() (set_to_none) -- keep .grad aliased to the flat buffer
+        for name, prm in self._params.items():
+            if prm.grad is None or prm.grad.data_ptr() != self.store.g[name].data_ptr():
+                prm.grad = self.store.g[name]
+
+    def train_step(self, samples, lr: float, weight_decay: float = 0.05, allreduce=None, world: int = 1):
+        """forward + backward (+ gradient all-reduce) + fused AdamW: one optimisation step of
+        `BaseTask._train_inner_loop` (base_task.py:233-271) without the autograd bridge."""
+        with torch.no_grad():
+            loss = self._forward_impl(samples, True)
+            self.backward()
+            if allreduce is not None:
+                allreduce(self.store.flat_g)
+            self.store.adamw_step(lr, weight_decay, grad_scale=1.0 / world)
+        return loss
+
+    @torch.no_grad()
+    def generate(self, samples, **generate_kwargs):
+        """`Myriad.generate` (myriad.py:433-454): stage 1 prompt layout, greedy decode (top_p=0.01 sampling of
+        evaluation_aqa_dataset.py:289-301 restated as arg-max), stop criterion on row 0."""
+        stage = 1 if self.arch == "myriad" else 0
+        image = samples["image"].to(self._dev, F32)
+        maps = None
+        if self.arch == "myriad":
+            key = "oneshot_anomaly_maps" if self.k_shot > 0 else "anomaly_maps"
+            maps = samples[key].to(self._dev, F32)
+        before, after, _, _ = self._tokenize(samples, image.shape[0], stage, False)
+        parts = self.encode_img(image, maps, stage, False)
+        emb, _, _, _ = self._assemble(parts, before, after, None, None)
+        emb = emb[:, 1:].contiguous()         # generate() wraps without BOS (myriad.py:446-449)
+        stops = generate_kwargs.get("stop_ids", ((835,), (2277, 29937)))
+        ids = self.llama.greedy_generate(emb, max_new_tokens=generate_kwargs.get("max_new_tokens", 90),
+                                         stop_ids=stops, min_length=generate_kwargs.get("min_length", 1),
+                                         eos_id=generate_kwargs.get("eos_token_id", 2))
+        return {"token_ids": ids, "ve_anomaly_maps": maps}
+
+
+class MiniGPT4HIP(MyriadHIP):
+    """`MiniGPT4` (reference mini_gpt4.py:14-307): ViT -> ln_vision -> Q-Former(32 queries) -> llama_proj -> LLaMA."""
+    arch = "mini_gpt4"
+
+
+registry.register_model("myriad")(MyriadHIP)
+registry.register_model("mini_gpt4")(MiniGPT4HIP)
+Myriad = MyriadHIP
+MiniGPT4 = MiniGPT4HIP

@@ -69,6 +69,22 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, b
     return out
 
 
+def gemm_auto_f32(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """f32 out = a @ b^T, choosing split-K when the output is small and the reduction long (wgrad shapes)."""
+    M, K = a.shape
+    N = b.shape[0]
+    tiles = ((M + 127) // 128) * ((N + 127) // 128)
+    kt = K // 64
+    if tiles >= 128 or kt < 16:
+        return gemm(a, b, out=out)
+    splits = max(1, min(kt // 4, 512 // tiles))
+    ws = torch.empty((_L().mh_gemm_splitk_ws_floats(M, N, splits),), dtype=F32, device=a.device)
+    rc = _L().mh_gemm_bf16_nt_splitk(_p(a), a.stride(0), _p(b), b.stride(0), _p(out), out.stride(0), M, N, K, splits,
+                                     _p(ws), _s())
+    _lib.check(rc, f"mh_gemm_bf16_nt_splitk M={M} N={N} K={K} splits={splits}")
+    return out
+
+
 # --------------------------------------------------------------------------- attention
 def attn_fwd(q, k, v, H: int, D: int, scale: float, causal: bool = False, bias=None, kv_len=None, out=None,
              need_lse: bool = True):
@@ -234,6 +250,28 @@ def gather_rows_bf16(src: torch.Tensor, rows: torch.Tensor):
     return out
 
 
+def gather_rows_f32(src: torch.Tensor, rows: torch.Tensor):
+    n, D = rows.numel(), src.shape[1]
+    out = torch.empty((n, D), dtype=F32, device=src.device)
+    _lib.check(_L().mh_gather_rows_f32(_p(src), src.stride(0), _p(rows), _p(out), n, D, _s()), "mh_gather_rows_f32")
+    return out
+
+
+def copy3d_bf16(src: torch.Tensor, dst: torch.Tensor):
+    nb, rows, cols = src.shape
+    _lib.check(_L().mh_copy3d_bf16(_p(src), src.stride(0), src.stride(1), _p(dst), dst.stride(0), dst.stride(1), nb,
+                                   rows, cols, _s()), "mh_copy3d_bf16")
+    return dst
+
+
+def patchify(img: torch.Tensor, P: int):
+    B, C, H, W = img.shape
+    Kpad = round_up(C * P * P, 64)
+    out = torch.empty((B * (H // P) * (W // P), Kpad), dtype=BF16, device=img.device)
+    _lib.check(_L().mh_patchify_nchw(_p(img), _p(out), B, C, H, W, P, Kpad, _s()), "mh_patchify_nchw")
+    return out
+
+
 def scatter_rows(src: torch.Tensor, rows: torch.Tensor, dst: torch.Tensor, accumulate: bool = False):
     n, D = src.shape
     _lib.check(_L().mh_scatter_rows_f32(_p(src), _p(rows), _p(dst), dst.stride(0), n, D, int(accumulate), _s()),
@@ -319,15 +357,18 @@ def col2im(dcol: torch.Tensor, B, H, W, C, kh, kw, pad):
 
 def relu_pool_fwd(y2d: torch.Tensor, B, H, W, C):
     p = torch.empty((B, H // 2, W // 2, C), dtype=BF16, device=y2d.device)
-    _lib.check(_L().mh_relu_maxpool2_fwd(_p(y2d), y2d.stride(0), _p(p), B, H, W, C, _s()), "mh_relu_maxpool2_fwd")
+    _lib.check(_L().mh_relu_maxpool2_fwd(_p(y2d), int(y2d.dtype == F32), y2d.stride(0), _p(p), B, H, W, C, _s()),
+               "mh_relu_maxpool2_fwd")
     return p
 
 
-def relu_pool_bwd(dp: torch.Tensor, y2d: torch.Tensor, B, H, W, C):
-    dy = torch.empty((B * H * W, C), dtype=BF16, device=y2d.device)
-    _lib.check(_L().mh_relu_maxpool2_bwd(_p(dp), _p(y2d), y2d.stride(0), _p(dy), dy.stride(0), B, H, W, C, _s()),
-               "mh_relu_maxpool2_bwd")
-    return dy
+def relu_pool_bwd(dp: torch.Tensor, y2d: torch.Tensor, B, H, W, C, pad_cols_to: int = 1):
+    """dy [B*H*W, C] bf16 (a view of a zero-padded [*, round_up(C,pad_cols_to)] buffer so it can be a GEMM A operand)."""
+    cpad = round_up(C, pad_cols_to)
+    full = (torch.zeros if cpad != C else torch.empty)((B * H * W, cpad), dtype=BF16, device=y2d.device)
+    _lib.check(_L().mh_relu_maxpool2_bwd(_p(dp), _p(y2d), int(y2d.dtype == F32), y2d.stride(0), _p(full),
+                                         full.stride(0), B, H, W, C, _s()), "mh_relu_maxpool2_bwd")
+    return full[:, :C], full
 
 
 def conv_pack(Wm: torch.Tensor, bias: Optional[torch.Tensor], out=None):

@@ -1,0 +1,125 @@
+"""CPU tests of the host logic: LR schedule, parameter grouping, flat parameter store layout, checkpoint-layout
+conversion, registry, synthetic-weight tables, and the N>1 data-parallel gradient exchange over gloo (world 2)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+from myriad_amd.myriad import ParamStore, uses_weight_decay
+from myriad_amd.networks import from_reference_layout, to_reference_layout, ve_param_specs
+from myriad_amd.registry import registry
+from myriad_amd.runner import DataParallel, LinearWarmupCosineLRScheduler
+from myriad_amd.synthetic import full_config, shape_table
+from oracle import myriad_ref as R
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def test_lr_scheduler_matches_reference_golden():
+    g = np.load(os.path.join(G, "optim.npz"))
+    s = LinearWarmupCosineLRScheduler(None, max_epoch=10, iters_per_epoch=1600, min_lr=0.0, init_lr=1e-4,
+                                      warmup_steps=0, warmup_start_lr=1e-6)
+    for (e, i), lr in zip(g["pts"].tolist(), g["lrs"].tolist()):
+        assert abs(s.step(e, i) - lr) <= 1e-12
+    s2 = LinearWarmupCosineLRScheduler(None, max_epoch=2, iters_per_epoch=100, min_lr=1e-5, init_lr=1e-3,
+                                       warmup_steps=20, warmup_start_lr=1e-6)
+    for (e, i), lr in zip(g["pts2"].tolist(), g["lrs2"].tolist()):
+        assert abs(s2.step(e, i) - lr) <= 1e-12
+    assert registry.get_lr_scheduler_class("linear_warmup_cosine_lr") is LinearWarmupCosineLRScheduler
+
+
+def test_registry_has_reference_model_names():
+    assert {"myriad", "mini_gpt4"} <= set(registry.list_models())
+
+
+def test_weight_decay_grouping_and_flat_store_layout():
+    specs = [("expert_adaptor.conv1.weight", (4, 1408), (4, 1408)), ("expert_adaptor.conv2.weight", (1408, 4), (1408, 4))]
+    specs += ve_param_specs("VETokenizer.", 4096, 5) + [("VETokenizer.base_prompts", (9, 4096), (9, 4096))]
+    specs += ve_param_specs("VEInstructor.", 768, 1)
+    for name, _, rshape in specs:
+        assert uses_weight_decay(name, len(rshape)) == R.uses_weight_decay(name, len(rshape))
+    st = ParamStore(specs, "cpu")
+    assert st.n_params() == 110_732_912            # trainable parameters of the shipped Myriad recipe
+    names = [s[0] for s in st.specs]
+    n_wd_names = [n for n in names if uses_weight_decay(n, len(st.ref_shape[n]))]
+    assert names[:len(n_wd_names)] == n_wd_names    # decay group first
+    off_first_nowd = st.offsets[names[len(n_wd_names)]][0]
+    assert off_first_nowd == st.n_wd and st.n_wd % 4 == 0 and st.total % 4 == 0
+    # views alias the flat buffers
+    st.p["VETokenizer.base_prompts"].fill_(3.0)
+    o, n = st.offsets["VETokenizer.base_prompts"]
+    assert float(st.flat_p[o:o + n].min()) == 3.0
+
+
+def test_conv_layout_round_trip():
+    w = torch.randn(16, 4, 3, 3)
+    m = from_reference_layout(w, (16, 36))
+    assert torch.equal(to_reference_layout(m, (16, 4, 3, 3)), w)
+    # GEMM order is (ky, kx, ci)
+    assert m[5, (1 * 3 + 2) * 4 + 3] == w[5, 3, 1, 2]
+
+
+def test_synthetic_table_matches_parameter_count():
+    t = shape_table(full_config(), "myriad")
+    n = 0
+    for k, (shape, _) in t.items():
+        if k.startswith("llama_model.model.layers.") or k in ("llama_model.lm_head.weight",
+                                                               "llama_model.model.embed_tokens.weight",
+                                                               "llama_model.model.norm.weight"):
+            c = 1
+            for s in shape:
+                c *= s
+            n += c
+    assert n == 6_738_415_616   # LLaMA-7B
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _dp_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)
+    flat = torch.randn(1000)
+    # rank-dependent "unused module": rank 0 skips segment [200,500), rank 1 skips [600,700)  => zeros (DDP
+    # find_unused_parameters semantics, reference runner_base.py:96-98 / myriad.py:378)
+    if rank == 0:
+        flat[200:500] = 0
+    else:
+        flat[600:700] = 0
+    mine = flat.clone()
+    dp = DataParallel(device=None)
+    assert dp.world == world and dp.rank == rank
+    dp.allreduce(flat)
+    q.put((rank, mine, flat))
+    dp.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, mine, red = q.get(timeout=120)
+        got[r] = (mine, red)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = R.allreduce_mean_reference([{"g": got[0][0]}, {"g": got[1][0]}])["g"] * 2   # sum; AdamW applies 1/world
+    for r in range(2):
+        assert torch.allclose(got[r][1], want, atol=1e-6)
+    assert torch.equal(got[0][1], got[1][1])

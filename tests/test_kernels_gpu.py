@@ -69,6 +69,20 @@ def test_gemm_epilogues_and_strides():
     assert wide[:, :8].abs().max() == 0 and wide[:, 8 + N:].abs().max() == 0
 
 
+@pytest.mark.parametrize("M,N,K", [(4, 64, 100352), (16, 64, 25088), (64, 192, 6272), (256, 576, 1600), (768, 1024, 128)])
+def test_gemm_splitk_wgrad_shapes(M, N, K):
+    a = bf(rnd(M, K, seed=7)).to(DEV)
+    b = bf(rnd(N, K, seed=8) + torch.arange(N)[:, None] * 1e-3).to(DEV)
+    ref = a.double() @ b.double().T
+    out = torch.empty(M, N, device=DEV)
+    ops.gemm_auto_f32(a, b, out)
+    assert relerr(out, ref) < 1e-4
+    # strided output (a view into a wider gradient buffer)
+    wide = torch.zeros(M, N + 8, device=DEV)
+    ops.gemm_auto_f32(a, b, wide[:, 4:4 + N])
+    assert relerr(wide[:, 4:4 + N], ref) < 1e-4 and wide[:, :4].abs().max() == 0
+
+
 def test_gemm_rejects_bad_k():
     a = bf(rnd(8, 40)).to(DEV)
     b = bf(rnd(8, 40)).to(DEV)

@@ -43,9 +43,11 @@ def cos_sim(a, b):
 def stem_grad_close(got, want):
     """First-layer conv-stem gradients are cancelling sums over ~1e5 positions behind 5 ReLU/arg-max layers: a
     bf16 forward flips a small fraction of those gates relative to the fp32 reference, which perturbs the sum by
-    O(10%) without any arithmetic error.  Stated tolerance: direction (cosine >= 0.95) and norm (within 15%)."""
+    O(10-20%) without any arithmetic error (test_ve_net_grads_vs_bf16_forward_emulation pins the arithmetic itself to
+    6e-2 / cosine 0.995 against an fp32 model with the same bf16 forward rounding).  Stated tolerance vs the fp32
+    golden: direction (cosine >= 0.9) and norm (within 25%)."""
     n_got, n_want = float(torch.as_tensor(got).norm()), float(torch.as_tensor(want).norm())
-    return cos_sim(got, want) >= 0.95 and abs(n_got - n_want) <= 0.15 * n_want
+    return cos_sim(got, want) >= 0.9 and abs(n_got - n_want) <= 0.25 * n_want
 
 
 def bf16_round(sd):
@@ -236,7 +238,8 @@ def test_networks_vs_golden():
         for idx in (0, 3, 6, 9, 12, 15):
             w = st.g[pre + f"meta_net.{idx}.weight"]
             want_norm = g[f"{nm}_dw{idx}_norm"].item()
-            assert abs(w.norm().item() - want_norm) < 5e-2 * want_norm, (nm, idx, w.norm().item(), want_norm)
+            tol = 0.25 if idx in (0, 3) else 5e-2       # first stem layers: see stem_grad_close
+            assert abs(w.norm().item() - want_norm) < tol * want_norm, (nm, idx, w.norm().item(), want_norm)
             assert stem_grad_close(st.g[pre + f"meta_net.{idx}.bias"][:64], g[f"{nm}_db{idx}"]), (nm, idx)
 
 
@@ -255,3 +258,41 @@ def test_train_step_moves_parameters_like_adamw(composite):
     assert relerr(model.store.flat_p, p_ref) < 1e-5
     loss1 = model.train_step(_samples(batch), lr=1e-3)
     assert float(loss1) < float(loss0)      # same batch, one AdamW step => loss goes down
+
+
+def test_ve_net_grads_vs_bf16_forward_emulation():
+    """Separates arithmetic error from forward-discontinuity sensitivity: an fp32 torch model whose FORWARD rounds
+    activations/weights to bf16 at the same points as the HIP path (straight-through in backward) must agree with
+    the HIP gradients tightly, including the first stem layer."""
+    import torch.nn.functional as F
+    from myriad_amd.myriad import ParamStore
+    from myriad_amd.networks import VENet, ve_param_specs
+
+    def ste(x):   # bf16 rounding, identity gradient
+        return x + (x.to(torch.bfloat16).float() - x).detach()
+
+    sd = gu.adapter_weights(seed=77, with_tokenizer=False)
+    specs = ve_param_specs("VEInstructor.", 768, 1)
+    st = ParamStore(specs, DEV)
+    for name, ishape, _ in st.specs:
+        st.p[name].copy_(from_reference_layout(sd[name].to(DEV), ishape))
+    gen = torch.Generator().manual_seed(5)
+    maps = torch.rand(2, 1, 224, 224, generator=gen).to(DEV)
+    ct = torch.randn(2, 49, 768, generator=gen).to(DEV)
+    net = VENet("VEInstructor.", 1, 768, st.p, st.g, DEV)
+    out = net.forward(maps)
+    net.backward(ct)
+    prm = {k: v.to(DEV).clone().requires_grad_(True) for k, v in sd.items() if k.startswith("VEInstructor.")}
+    x = ste(maps)
+    for idx in (0, 3, 6, 9, 12):
+        y = F.conv2d(x, ste(prm[f"VEInstructor.meta_net.{idx}.weight"]), ste(prm[f"VEInstructor.meta_net.{idx}.bias"]), padding=1)
+        x = ste(F.max_pool2d(F.relu(y), 2))
+    y = F.conv2d(x, ste(prm["VEInstructor.meta_net.15.weight"]), prm["VEInstructor.meta_net.15.bias"])
+    ref = y.reshape(2, 768, 49).transpose(-2, -1)
+    assert relerr(out, ref) < 2e-3
+    (ref * ct).sum().backward()
+    for idx, (ci, co) in zip((0, 3, 6, 9, 12), [(1, 4), (4, 16), (16, 64), (64, 256), (256, 1024)]):
+        want = prm[f"VEInstructor.meta_net.{idx}.weight"].grad.permute(0, 2, 3, 1).reshape(co, 9 * ci)
+        got = st.g[f"VEInstructor.meta_net.{idx}.weight"]
+        assert cos_sim(got, want) > 0.995 and relerr(got, want) < 6e-2, (idx, cos_sim(got, want), relerr(got, want))
+        assert relerr(st.g[f"VEInstructor.meta_net.{idx}.bias"], prm[f"VEInstructor.meta_net.{idx}.bias"].grad) < 6e-2, idx

@@ -81,7 +81,7 @@ class GemmProbe:
             e0.record()
             out = self.orig(a, b, *args, **kw)
             e1.record()
-            self.records.append((e0, e1, 2.0 * a.shape[0] * b.shape[0] * a.shape[1]))
+            self.records.append((e0, e1, 2.0 * a.shape[0] * b.shape[0] * a.shape[1], (a.shape[0], b.shape[0], a.shape[1])))
             return out
 
         ops.gemm = timed
@@ -96,9 +96,16 @@ class GemmProbe:
 
     def summary(self):
         torch.cuda.synchronize()
-        t_ms = sum(e0.elapsed_time(e1) for e0, e1, _ in self.records)
-        fl = sum(f for _, _, f in self.records)
+        t_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.records)
+        fl = sum(f for _, _, f, _ in self.records)
         n = len(self.records)
+        shapes = {}
+        for e0, e1, f, shp in self.records:
+            d = shapes.setdefault(shp, [0, 0.0, 0.0])
+            d[0] += 1
+            d[1] += e0.elapsed_time(e1)
+            d[2] += f
+        self.shapes = sorted(((k, v[0], v[1], v[2] / (v[1] * 1e-3) / 1e12) for k, v in shapes.items()), key=lambda r: -r[2])
         return dict(launches=n, total_ms=t_ms, avg_us=1e3 * t_ms / max(n, 1), tflops=fl / (t_ms * 1e-3) / 1e12 if t_ms else 0.0,
                     flops=fl)
 
@@ -232,6 +239,11 @@ def main():
         with GemmProbe() as pr:
             step(a.warmup + a.steps)
             gs = pr.summary()
+        if os.environ.get("BENCH_SHAPES"):
+            with open(os.environ["BENCH_SHAPES"], "w") as f:
+                f.write("M,N,K,launches,total_ms,TFLOPs\n")
+                for (m, n, k), cnt, ms, tf in pr.shapes:
+                    f.write(f"{m},{n},{k},{cnt},{ms:.3f},{tf:.1f}\n")
         roof = dict(bound="mfma", kernel="gemm_nt_kernel<glds> (mh_gemm_bf16_nt)", achieved=round(gs["tflops"], 1),
                     peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(gs["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=None,
                     launches_per_step=gs["launches"], avg_launch_us=round(gs["avg_us"], 2),

@@ -5,20 +5,25 @@
 // modeling_llama.py:134-136,159-162,604).  dgrad uses the same kernel on pre-transposed frozen weights
 // (W^T stored [in,out]); wgrad uses it on transposed activations.  One kernel, one layout.
 //
-// gfx950 design: 128x128x64 block tile, 4 waves (2x2), each wave a 64x64 sub-tile as 4x4
-// v_mfma_f32_16x16x32_bf16 fragments (fp32 accumulate, 64 acc VGPRs).  A/B tiles are staged into LDS by
+// gfx950 design: 128 x TBN x 64 block tile (TBN = 128 or 64), 4 waves (2x2), each wave a 64 x TBN/2 sub-tile of
+// v_mfma_f32_16x16x32_bf16 fragments (fp32 accumulate).  A/B tiles are staged into LDS by
 // global_load_lds_dwordx4 (LDS-DMA, 16 B/lane, no VGPR round trip), double-buffered; the LDS image is
 // lane-linear, so the bank-conflict XOR swizzle (16-B chunk ^= row&7) is applied on the per-lane global
 // SOURCE address and again on the ds_read_b128 fragment reads.  The MFMA is issued as (B-frag, A-frag) so
 // each lane ends up with 4 consecutive N for one M row -> 8/16-byte vector epilogue stores with
 // vector bias/residual loads.  Workgroup ids are remapped so each XCD (private L2) owns a contiguous
 // run of tiles that share the same weight panel.
+//
+// Tile-width choice (measured, profiles/): the fine-tune step has M = B*S ~ 1.2-2k rows, so N = 4096 / 1408
+// outputs give only 187-320 128x128 tiles for 256 CUs x 2 resident blocks; those shapes run at 360-650 TF/s while
+// >= 512-tile shapes reach 780-840.  TBN = 64 doubles the tile count (3 resident blocks per CU at 48 KiB LDS) so
+// the per-k-step vmcnt(0)+barrier drain of one block is covered by its neighbours.  Row fragments that lie
+// entirely beyond M (the ragged last M tile) skip their ds_reads and MFMAs.
 #include "common.h"
 
 #define BM 128
-#define BN 128
 #define BK 64
-#define STAGE_BYTES (BM * BK * 2)  // one operand tile: 16 KiB
+#define A_STAGE_BYTES (BM * BK * 2)  // 16 KiB
 
 #define MH_GEMM_OUT_F32 1
 #define MH_GEMM_GELU 2
@@ -29,13 +34,17 @@ typedef const __attribute__((address_space(1))) void gbl_void_t;
 
 __device__ __forceinline__ int swz_off(int row, int chunk) { return row * (BK * 2) + ((chunk ^ (row & 7)) << 4); }
 
-template <bool GLDS>
+template <bool GLDS, int TBN>
 __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                         void* Cv, const float* __restrict__ bias,
-                                                         const float* res, int M, int N, int K, int lda, int ldb,
-                                                         int ldc, int ldr, int flags, float alpha, int tiles_m,
-                                                         int kt_per_split, long split_stride) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A 16K | B 16K]
+                                                         void* Cv, const float* __restrict__ bias, const float* res,
+                                                         int M, int N, int K, int lda, int ldb, int ldc, int ldr,
+                                                         int flags, float alpha, int tiles_m, int kt_per_split,
+                                                         long split_stride) {
+  constexpr int NJ = TBN / 32;                 // 16-wide N fragments per wave
+  constexpr int NB = TBN / 32;                 // B staging chunks per thread (TBN rows x 8 chunks / 256 threads)
+  constexpr int B_STAGE_BYTES = TBN * BK * 2;
+  constexpr int STAGE = A_STAGE_BYTES + B_STAGE_BYTES;
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A | B]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -47,64 +56,73 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   const int tm = lid % tiles_m, tn = lid / tiles_m;
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BM, n0 = tn * TBN;
 
-  // per-thread staging coordinates: 4 chunks of 16 B per operand tile
   const bf16_t* gA[4];
-  const bf16_t* gB[4];
+  const bf16_t* gB[NB];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     const int c = i * 256 + tid;
     const int row = c >> 3, lc = (c & 7) ^ (row & 7);
     int ra = m0 + row;
     ra = ra < M ? ra : M - 1;
+    gA[i] = A + (size_t)ra * lda + lc * 8;
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) {
+    const int c = i * 256 + tid;
+    const int row = c >> 3, lc = (c & 7) ^ (row & 7);
     int rb = n0 + row;
     rb = rb < N ? rb : N - 1;
-    gA[i] = A + (size_t)ra * lda + lc * 8;
     gB[i] = B + (size_t)rb * ldb + lc * 8;
   }
 
-  float4_t acc[4][4];
+  float4_t acc[4][NJ];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NJ; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
   // split-K: blockIdx.y owns K tiles [kt0, kt0+nt) and writes its fp32 partial slab at Cv + y*split_stride
   const int nt_all = K / BK;
   const int kt0 = blockIdx.y * kt_per_split;
   const int nt = (nt_all - kt0) < kt_per_split ? (nt_all - kt0) : kt_per_split;
   if (gridDim.y > 1) Cv = reinterpret_cast<float*>(Cv) + blockIdx.y * split_stride;
-  short8_t ra_[4], rb_[4];
+  // number of 16-row fragments of this wave that contain at least one valid row (ragged last M tile)
+  int vrows = M - (m0 + wm * 64);
+  const int ni = vrows >= 64 ? 4 : (vrows <= 0 ? 0 : (vrows + 15) >> 4);
+
+  short8_t ra_[4], rb_[NB];
 
   auto issue = [&](int t, int buf) {
-    char* sA = smem + buf * 2 * STAGE_BYTES;
-    char* sB = sA + STAGE_BYTES;
+    char* sA = smem + buf * STAGE;
+    char* sB = sA + A_STAGE_BYTES;
     const int k0 = (kt0 + t) * BK;
     if (GLDS) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int base = (i * 256 + wave * 64) * 16;
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(gA[i] + k0), (lds_void_t*)(sA + base), 16, 0, 0);
+      }
+#pragma unroll
+      for (int i = 0; i < NB; ++i) {
+        const int base = (i * 256 + wave * 64) * 16;
         __builtin_amdgcn_global_load_lds((gbl_void_t*)(gB[i] + k0), (lds_void_t*)(sB + base), 16, 0, 0);
       }
     } else {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        ra_[i] = *reinterpret_cast<const short8_t*>(gA[i] + k0);
-        rb_[i] = *reinterpret_cast<const short8_t*>(gB[i] + k0);
-      }
+      for (int i = 0; i < 4; ++i) ra_[i] = *reinterpret_cast<const short8_t*>(gA[i] + k0);
+#pragma unroll
+      for (int i = 0; i < NB; ++i) rb_[i] = *reinterpret_cast<const short8_t*>(gB[i] + k0);
     }
   };
   auto commit = [&](int buf) {  // register-staged path only
-    char* sA = smem + buf * 2 * STAGE_BYTES;
-    char* sB = sA + STAGE_BYTES;
+    char* sA = smem + buf * STAGE;
+    char* sB = sA + A_STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int off = (i * 256 + tid) * 16;
-      *reinterpret_cast<short8_t*>(sA + off) = ra_[i];
-      *reinterpret_cast<short8_t*>(sB + off) = rb_[i];
-    }
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<short8_t*>(sA + (i * 256 + tid) * 16) = ra_[i];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) *reinterpret_cast<short8_t*>(sB + (i * 256 + tid) * 16) = rb_[i];
   };
 
   issue(0, 0);
@@ -118,21 +136,42 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
   for (int t = 0; t < nt; ++t) {
     const int buf = t & 1;
     if (t + 1 < nt) issue(t + 1, buf ^ 1);
-    const char* sA = smem + buf * 2 * STAGE_BYTES;
-    const char* sB = sA + STAGE_BYTES;
+    const char* sA = smem + buf * STAGE;
+    const char* sB = sA + A_STAGE_BYTES;
+    if (ni == 4) {   // common case: straight-line, fully unrolled (no predication in the MFMA stream)
 #pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
-      short8_t af[4], bfr[4];
+      for (int kk = 0; kk < 2; ++kk) {
+        short8_t af[4], bfr[NJ];
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        af[i] = *reinterpret_cast<const short8_t*>(sA + swz_off(wm * 64 + i * 16 + lr, kk * 4 + lg));
-        bfr[i] = *reinterpret_cast<const short8_t*>(sB + swz_off(wn * 64 + i * 16 + lr, kk * 4 + lg));
+        for (int j = 0; j < NJ; ++j)
+          bfr[j] = *reinterpret_cast<const short8_t*>(sB + swz_off(wn * (TBN / 2) + j * 16 + lr, kk * 4 + lg));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          af[i] = *reinterpret_cast<const short8_t*>(sA + swz_off(wm * 64 + i * 16 + lr, kk * 4 + lg));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
       }
+    } else if (ni > 0) {   // ragged last M tile: only the fragments that hold valid rows
 #pragma unroll
-      for (int i = 0; i < 4; ++i)
+      for (int kk = 0; kk < 2; ++kk) {
+        short8_t af[4], bfr[NJ];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        for (int j = 0; j < NJ; ++j)
+          bfr[j] = *reinterpret_cast<const short8_t*>(sB + swz_off(wn * (TBN / 2) + j * 16 + lr, kk * 4 + lg));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < ni) af[i] = *reinterpret_cast<const short8_t*>(sA + swz_off(wm * 64 + i * 16 + lr, kk * 4 + lg));
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          if (i < ni) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+          }
+      }
     }
     if (GLDS) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -142,7 +181,7 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
     __syncthreads();
   }
 
-  // epilogue: lane owns C[m][n .. n+3] for m = m0+wm*64+i*16+lr, n = n0+wn*64+j*16+lg*4
+  // epilogue: lane owns C[m][n .. n+3] for m = m0+wm*64+i*16+lr, n = n0+wn*(TBN/2)+j*16+lg*4
   const bool out_f32 = flags & MH_GEMM_OUT_F32;
   const bool do_gelu = flags & MH_GEMM_GELU;
 #pragma unroll
@@ -150,8 +189,8 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
     const int m = m0 + wm * 64 + i * 16 + lr;
     if (m >= M) continue;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int n = n0 + wn * 64 + j * 16 + lg * 4;
+    for (int j = 0; j < NJ; ++j) {
+      const int n = n0 + wn * (TBN / 2) + j * 16 + lg * 4;
       if (n >= N) continue;
       float v[4] = {acc[i][j][0] * alpha, acc[i][j][1] * alpha, acc[i][j][2] * alpha, acc[i][j][3] * alpha};
       if (n + 3 < N) {
@@ -190,33 +229,46 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
   }
 }
 
+template <bool GLDS, int TBN>
+static int launch_gemm(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                       const float* bias, const float* residual, int ldr, int flags, float alpha, int splits, int tps,
+                       long split_stride, hipStream_t stream) {
+  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + TBN - 1) / TBN;
+  const dim3 grid(tiles_m * tiles_n, splits), block(256);
+  const size_t shmem = 2 * (A_STAGE_BYTES + TBN * BK * 2);
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<GLDS, TBN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)shmem);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm_nt_kernel<GLDS, TBN>), grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)B, C,
+                     bias, residual, M, N, K, lda, ldb, ldc, ldr, flags, alpha, tiles_m, tps, split_stride);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// 128-wide N tiles when they already give >= ~1.75 resident blocks per CU, else 64-wide
+static inline bool use_narrow(int M, int N) {
+  const long tiles128 = (long)((M + BM - 1) / BM) * ((N + 127) / 128);
+  return tiles128 < 448;
+}
+
 extern "C" int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                                const float* bias, const float* residual, int ldr, int flags, float alpha,
                                hipStream_t stream) {
   if (M <= 0 || N <= 0) return MH_OK;
   if (K <= 0 || (K % BK) != 0 || (lda % 8) != 0 || (ldb % 8) != 0) return MH_ERR_ARG;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15)) return MH_ERR_ARG;
-  const bool f32 = flags & MH_GEMM_OUT_F32;
   if ((ldc % 4) != 0 || (residual && (ldr % 4) != 0)) return MH_ERR_ARG;
-  (void)f32;
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  const dim3 grid(tiles_m * tiles_n), block(256);
-  const size_t shmem = 4 * STAGE_BYTES;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-    attr_set = true;
-  }
+  const int nt = K / BK;
+  const bool narrow = use_narrow(M, N);
   if (flags & MH_GEMM_REGSTAGE) {
-    hipLaunchKernelGGL(gemm_nt_kernel<false>, grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)B, C, bias,
-                       residual, M, N, K, lda, ldb, ldc, ldr, flags, alpha, tiles_m, K / BK, 0L);
-  } else {
-    hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)B, C, bias,
-                       residual, M, N, K, lda, ldb, ldc, ldr, flags, alpha, tiles_m, K / BK, 0L);
+    return narrow ? launch_gemm<false, 64>(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, flags, alpha, 1, nt, 0L, stream)
+                  : launch_gemm<false, 128>(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, flags, alpha, 1, nt, 0L, stream);
   }
-  MH_CHECK_LAUNCH();
-  return MH_OK;
+  return narrow ? launch_gemm<true, 64>(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, flags, alpha, 1, nt, 0L, stream)
+                : launch_gemm<true, 128>(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, flags, alpha, 1, nt, 0L, stream);
 }
 
 // ---- split-K variant for skinny outputs with a long reduction (wgrad of the conv stem, M,N small, K huge) ----
@@ -242,14 +294,9 @@ extern "C" int mh_gemm_bf16_nt_splitk(const void* A, int lda, const void* B, int
   if (splits > nt) splits = nt;
   const int tps = (nt + splits - 1) / splits;
   splits = (nt + tps - 1) / tps;
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + BN - 1) / BN;
-  const dim3 grid(tiles_m * tiles_n, splits), block(256);
-  const size_t shmem = 4 * STAGE_BYTES;
-  (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
-  hipLaunchKernelGGL(gemm_nt_kernel<true>, grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)B, (void*)ws,
-                     (const float*)nullptr, (const float*)nullptr, M, N, K, lda, ldb, N, 0, MH_GEMM_OUT_F32, 1.0f, tiles_m,
-                     tps, (long)M * N);
-  MH_CHECK_LAUNCH();
+  int rc = launch_gemm<true, 128>(A, lda, B, ldb, (void*)ws, N, M, N, K, nullptr, nullptr, 0, MH_GEMM_OUT_F32, 1.0f, splits,
+                                  tps, (long)M * N, stream);
+  if (rc) return rc;
   long g = ((long)M * N + 255) / 256;
   if (g > 4096) g = 4096;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, stream, ws, C, M, N, ldc, splits);

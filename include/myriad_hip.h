@@ -35,6 +35,9 @@ typedef struct ihipStream_t* mh_stream_t; /* == hipStream_t */
 int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                     const float* bias, const float* residual, int ldr, int flags, float alpha, mh_stream_t s);
 
+/* Scratch for the automatic split-K path of mh_gemm_bf16_nt (used for shapes whose tile count under-fills the
+ * 256 CUs).  The caller owns the buffer; pass NULL to disable.  Not needed for correctness. */
+int mh_set_workspace(void* ptr, long bytes);
 /* split-K variant (f32 out, no epilogue) for skinny outputs with a long reduction (conv-stem wgrad):
  * ws holds mh_gemm_splitk_ws_floats(M,N,splits) floats; fixed-order reduction -> deterministic. */
 long mh_gemm_splitk_ws_floats(int M, int N, int splits);

@@ -7,48 +7,75 @@
 //
 // gfx950 design: 128 x TBN x 64 block tile (TBN = 128 or 64), 4 waves (2x2), each wave a 64 x TBN/2 sub-tile of
 // v_mfma_f32_16x16x32_bf16 fragments (fp32 accumulate).  A/B tiles are staged into LDS by
-// global_load_lds_dwordx4 (LDS-DMA, 16 B/lane, no VGPR round trip), double-buffered; the LDS image is
-// lane-linear, so the bank-conflict XOR swizzle (16-B chunk ^= row&7) is applied on the per-lane global
-// SOURCE address and again on the ds_read_b128 fragment reads.  The MFMA is issued as (B-frag, A-frag) so
-// each lane ends up with 4 consecutive N for one M row -> 8/16-byte vector epilogue stores with
-// vector bias/residual loads.  Workgroup ids are remapped so each XCD (private L2) owns a contiguous
-// run of tiles that share the same weight panel.
-//
-// Tile-width choice (measured, profiles/): the fine-tune step has M = B*S ~ 1.2-2k rows, so N = 4096 / 1408
-// outputs give only 187-320 128x128 tiles for 256 CUs x 2 resident blocks; those shapes run at 360-650 TF/s while
-// >= 512-tile shapes reach 780-840.  TBN = 64 doubles the tile count (3 resident blocks per CU at 48 KiB LDS) so
-// the per-k-step vmcnt(0)+barrier drain of one block is covered by its neighbours.  Row fragments that lie
-// entirely beyond M (the ragged last M tile) skip their ds_reads and MFMAs.
+// global_load_lds_dwordx4 (LDS-DMA, 16 B/lane, no VGPR round trip) through an NST-deep LDS ring with COUNTED
+// s_waitcnt vmcnt(N) and a raw s_barrier, so NST-1 K-tiles of loads stay in flight across barriers (the 2-deep
+// vmcnt(0)+__syncthreads form measured 560-840 TF/s on the step's shapes: one K-step of MFMA work, ~512
+// cycles, cannot cover a ~2k-cycle loaded L2/HBM round trip).  The LDS image is lane-linear, so the bank-conflict
+// XOR swizzle (16-B chunk ^= row&7) is applied on the per-lane global SOURCE address and again on the
+// ds_read_b128 fragment reads.  The MFMA is issued as (B-frag, A-frag) so each lane ends up with 4 consecutive N
+// for one M row -> 8/16-byte vector epilogue stores with vector bias/residual loads.  Workgroup ids are remapped so
+// each XCD (private L2) owns a contiguous run of tiles that share the same weight panel.
 #include "common.h"
 
 #define BM 128
-#define BK 64
-#define A_STAGE_BYTES (BM * BK * 2)  // 16 KiB
+#define BKMIN 32   // K must be a multiple of 64 at the ABI; kernels use 64- or 32-deep K tiles
 
 #define MH_GEMM_OUT_F32 1
 #define MH_GEMM_GELU 2
 #define MH_GEMM_REGSTAGE 4
+#define MH_GEMM_VARIANT_SHIFT 8  // bits 8..11: 0 = auto, 1 = 2-stage/128, 2 = 4-stage/128, 3 = 3-stage/64, 4 = 2-stage/64
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
 
-__device__ __forceinline__ int swz_off(int row, int chunk) { return row * (BK * 2) + ((chunk ^ (row & 7)) << 4); }
+// byte offset of 16-B chunk `chunk` of tile row `row` in the swizzled LDS image (rows are TBK*2 bytes)
+template <int TBK>
+__device__ __forceinline__ int swz_off(int row, int chunk) {
+  if (TBK == 64) return row * 128 + ((chunk ^ (row & 7)) << 4);
+  return row * 64 + ((chunk ^ ((row >> 2) & 3)) << 4);   // 64-B rows: rows r, r+4, r+8, r+12 share banks
+}
+template <int TBK>
+__device__ __forceinline__ int swz_src_chunk(int row, int phys) {
+  return TBK == 64 ? (phys ^ (row & 7)) : (phys ^ ((row >> 2) & 3));
+}
 
-template <bool GLDS, int TBN>
-__global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
-                                                         void* Cv, const float* __restrict__ bias, const float* res,
-                                                         int M, int N, int K, int lda, int ldb, int ldc, int ldr,
-                                                         int flags, float alpha, int tiles_m, int kt_per_split,
-                                                         long split_stride) {
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  static_assert(N == 0 || N == 3 || N == 4 || N == 6 || N == 8 || N == 12 || N == 16, "unsupported count");
+  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+  if (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+}
+
+// STAGING: 0 = LDS-DMA ring (NST stages), 1 = register-staged double buffer (NST must be 2; A/B-test reference)
+template <int STAGING, int NST, int TBN, int MINB, int TBK, int NW>
+__global__ __launch_bounds__(NW * 64, MINB * NW / 4) void gemm_nt_kernel(const bf16_t* __restrict__ A,
+                                                            const bf16_t* __restrict__ B, void* Cv,
+                                                            const float* __restrict__ bias, const float* res, int M,
+                                                            int N, int K, int lda, int ldb, int ldc, int ldr, int flags,
+                                                            float alpha, int tiles_m, int kt_per_split,
+                                                            long split_stride) {
+  constexpr int BK = TBK;
+  constexpr int CPR = TBK / 8;                 // 16-B chunks per tile row
   constexpr int NJ = TBN / 32;                 // 16-wide N fragments per wave
-  constexpr int NB = TBN / 32;                 // B staging chunks per thread (TBN rows x 8 chunks / 256 threads)
+  constexpr int NT = NW * 64;                  // threads per workgroup
+  constexpr int WROWS = NW / 2;                // waves along M (x 2 along N)
+  constexpr int MI = BM / WROWS / 16;          // 16-row M fragments per wave (4 for 4 waves, 2 for 8 waves)
+  constexpr int NA = BM * CPR / NT;            // A staging chunks per thread
+  constexpr int NB = TBN * CPR / NT;           // B staging chunks per thread
+  constexpr int LPT = NA + NB;                 // LDS-DMA instructions per thread per K tile
+  constexpr int A_STAGE_BYTES = BM * BK * 2;
   constexpr int B_STAGE_BYTES = TBN * BK * 2;
   constexpr int STAGE = A_STAGE_BYTES + B_STAGE_BYTES;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][A | B]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [NST stages][A | B]
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave >> 1, wn = wave & 1;   // wave grid WROWS x 2
   const int lr = lane & 15, lg = lane >> 4;
 
   // XCD-aware bijective remap: blocks b, b+8, b+16.. land on one XCD -> give them consecutive tiles.
@@ -58,28 +85,28 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
   const int tm = lid % tiles_m, tn = lid / tiles_m;
   const int m0 = tm * BM, n0 = tn * TBN;
 
-  const bf16_t* gA[4];
+  const bf16_t* gA[NA];
   const bf16_t* gB[NB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int c = i * 256 + tid;
-    const int row = c >> 3, lc = (c & 7) ^ (row & 7);
+  for (int i = 0; i < NA; ++i) {
+    const int c = i * NT + tid;
+    const int row = c / CPR, lc = swz_src_chunk<TBK>(row, c % CPR);
     int ra = m0 + row;
     ra = ra < M ? ra : M - 1;
     gA[i] = A + (size_t)ra * lda + lc * 8;
   }
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
-    const int c = i * 256 + tid;
-    const int row = c >> 3, lc = (c & 7) ^ (row & 7);
+    const int c = i * NT + tid;
+    const int row = c / CPR, lc = swz_src_chunk<TBK>(row, c % CPR);
     int rb = n0 + row;
     rb = rb < N ? rb : N - 1;
     gB[i] = B + (size_t)rb * ldb + lc * 8;
   }
 
-  float4_t acc[4][NJ];
+  float4_t acc[MI][NJ];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < MI; ++i)
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
 
@@ -88,105 +115,96 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
   const int kt0 = blockIdx.y * kt_per_split;
   const int nt = (nt_all - kt0) < kt_per_split ? (nt_all - kt0) : kt_per_split;
   if (gridDim.y > 1) Cv = reinterpret_cast<float*>(Cv) + blockIdx.y * split_stride;
-  // number of 16-row fragments of this wave that contain at least one valid row (ragged last M tile)
-  int vrows = M - (m0 + wm * 64);
-  const int ni = vrows >= 64 ? 4 : (vrows <= 0 ? 0 : (vrows + 15) >> 4);
 
-  short8_t ra_[4], rb_[NB];
-
-  auto issue = [&](int t, int buf) {
-    char* sA = smem + buf * STAGE;
+  auto issue_dma = [&](int t, int stage) {
+    char* sA = smem + stage * STAGE;
     char* sB = sA + A_STAGE_BYTES;
     const int k0 = (kt0 + t) * BK;
-    if (GLDS) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int base = (i * 256 + wave * 64) * 16;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(gA[i] + k0), (lds_void_t*)(sA + base), 16, 0, 0);
+    for (int i = 0; i < NA; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(gA[i] + k0), (lds_void_t*)(sA + (i * NT + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < NB; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(gB[i] + k0), (lds_void_t*)(sB + (i * NT + wave * 64) * 16), 16, 0, 0);
+  };
+  auto compute = [&](int stage) {
+    const char* sA = smem + stage * STAGE;
+    const char* sB = sA + A_STAGE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < TBK / 32; ++kk) {
+      short8_t af[MI], bfr[NJ];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        bfr[j] = *reinterpret_cast<const short8_t*>(sB + swz_off<TBK>(wn * (TBN / 2) + j * 16 + lr, kk * 4 + lg));
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+        af[i] = *reinterpret_cast<const short8_t*>(sA + swz_off<TBK>(wm * (MI * 16) + i * 16 + lr, kk * 4 + lg));
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    }
+  };
+
+  if (STAGING == 0) {
+    // ---- LDS-DMA ring: tiles t+1 .. t+NST-1 are in flight while tile t is multiplied ----
+    const int pre = (NST - 1) < nt ? (NST - 1) : nt;
+    for (int t = 0; t < pre; ++t) issue_dma(t, t);
+    int stage = 0;
+    for (int t = 0; t < nt; ++t) {
+      // loads issued after tile t's own: LPT * (tiles in flight behind it)
+      const int issued = (t + NST - 1) < nt ? (t + NST - 1) : nt;
+      const int behind = issued - (t + 1);
+      if (NST >= 4 && behind >= 2) wait_vmcnt<2 * LPT>();
+      else if (NST >= 3 && behind >= 1) wait_vmcnt<LPT>();
+      else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // tile t visible to all waves; everyone is done reading stage (t-1)%NST
+      if (t + NST - 1 < nt) {
+        int ps = stage + NST - 1;
+        ps = ps >= NST ? ps - NST : ps;
+        issue_dma(t + NST - 1, ps);
       }
+      compute(stage);
+      stage = (stage + 1 == NST) ? 0 : stage + 1;
+    }
+  } else {
+    // ---- register-staged double buffer (reference structure for A/B tests) ----
+    short8_t ra_[NA], rb_[NB];
+    auto load_regs = [&](int t) {
+      const int k0 = (kt0 + t) * BK;
 #pragma unroll
-      for (int i = 0; i < NB; ++i) {
-        const int base = (i * 256 + wave * 64) * 16;
-        __builtin_amdgcn_global_load_lds((gbl_void_t*)(gB[i] + k0), (lds_void_t*)(sB + base), 16, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) ra_[i] = *reinterpret_cast<const short8_t*>(gA[i] + k0);
+      for (int i = 0; i < NA; ++i) ra_[i] = *reinterpret_cast<const short8_t*>(gA[i] + k0);
 #pragma unroll
       for (int i = 0; i < NB; ++i) rb_[i] = *reinterpret_cast<const short8_t*>(gB[i] + k0);
-    }
-  };
-  auto commit = [&](int buf) {  // register-staged path only
-    char* sA = smem + buf * STAGE;
-    char* sB = sA + A_STAGE_BYTES;
+    };
+    auto commit = [&](int buf) {
+      char* sA = smem + buf * STAGE;
+      char* sB = sA + A_STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) *reinterpret_cast<short8_t*>(sA + (i * 256 + tid) * 16) = ra_[i];
+      for (int i = 0; i < NA; ++i) *reinterpret_cast<short8_t*>(sA + (i * NT + tid) * 16) = ra_[i];
 #pragma unroll
-    for (int i = 0; i < NB; ++i) *reinterpret_cast<short8_t*>(sB + (i * 256 + tid) * 16) = rb_[i];
-  };
-
-  issue(0, 0);
-  if (GLDS) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  } else {
+      for (int i = 0; i < NB; ++i) *reinterpret_cast<short8_t*>(sB + (i * NT + tid) * 16) = rb_[i];
+    };
+    load_regs(0);
     commit(0);
-  }
-  __syncthreads();
-
-  for (int t = 0; t < nt; ++t) {
-    const int buf = t & 1;
-    if (t + 1 < nt) issue(t + 1, buf ^ 1);
-    const char* sA = smem + buf * STAGE;
-    const char* sB = sA + A_STAGE_BYTES;
-    if (ni == 4) {   // common case: straight-line, fully unrolled (no predication in the MFMA stream)
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        short8_t af[4], bfr[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          bfr[j] = *reinterpret_cast<const short8_t*>(sB + swz_off(wn * (TBN / 2) + j * 16 + lr, kk * 4 + lg));
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          af[i] = *reinterpret_cast<const short8_t*>(sA + swz_off(wm * 64 + i * 16 + lr, kk * 4 + lg));
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-      }
-    } else if (ni > 0) {   // ragged last M tile: only the fragments that hold valid rows
-#pragma unroll
-      for (int kk = 0; kk < 2; ++kk) {
-        short8_t af[4], bfr[NJ];
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          bfr[j] = *reinterpret_cast<const short8_t*>(sB + swz_off(wn * (TBN / 2) + j * 16 + lr, kk * 4 + lg));
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (i < ni) af[i] = *reinterpret_cast<const short8_t*>(sA + swz_off(wm * 64 + i * 16 + lr, kk * 4 + lg));
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-          if (i < ni) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
-          }
-      }
-    }
-    if (GLDS) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    } else {
-      if (t + 1 < nt) commit(buf ^ 1);
-    }
     __syncthreads();
+    for (int t = 0; t < nt; ++t) {
+      const int buf = t & 1;
+      if (t + 1 < nt) load_regs(t + 1);
+      compute(buf);
+      if (t + 1 < nt) commit(buf ^ 1);
+      __syncthreads();
+    }
   }
 
   // epilogue: lane owns C[m][n .. n+3] for m = m0+wm*64+i*16+lr, n = n0+wn*(TBN/2)+j*16+lg*4
   const bool out_f32 = flags & MH_GEMM_OUT_F32;
   const bool do_gelu = flags & MH_GEMM_GELU;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + wm * 64 + i * 16 + lr;
+  for (int i = 0; i < MI; ++i) {
+    const int m = m0 + wm * (MI * 16) + i * 16 + lr;
     if (m >= M) continue;
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
@@ -229,77 +247,156 @@ __global__ __launch_bounds__(256, 2) void gemm_nt_kernel(const bf16_t* __restric
   }
 }
 
-template <bool GLDS, int TBN>
-static int launch_gemm(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
-                       const float* bias, const float* residual, int ldr, int flags, float alpha, int splits, int tps,
-                       long split_stride, hipStream_t stream) {
-  const int tiles_m = (M + BM - 1) / BM, tiles_n = (N + TBN - 1) / TBN;
-  const dim3 grid(tiles_m * tiles_n, splits), block(256);
-  const size_t shmem = 2 * (A_STAGE_BYTES + TBN * BK * 2);
+struct GemmArgs {
+  const void* A; int lda; const void* B; int ldb; void* C; int ldc; int M, N, K;
+  const float* bias; const float* residual; int ldr; int flags; float alpha; int splits, tps; long split_stride;
+};
+
+template <int STAGING, int NST, int TBN, int MINB, int TBK = 64, int NW = 4>
+static int launch_gemm(const GemmArgs& g, hipStream_t stream) {
+  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + TBN - 1) / TBN;
+  const dim3 grid(tiles_m * tiles_n, g.splits), block(NW * 64);
+  const size_t shmem = (size_t)NST * (BM + TBN) * TBK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<GLDS, TBN>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                              (int)shmem);
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<STAGING, NST, TBN, MINB, TBK, NW>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     attr_set = true;
   }
-  hipLaunchKernelGGL((gemm_nt_kernel<GLDS, TBN>), grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)B, C,
-                     bias, residual, M, N, K, lda, ldb, ldc, ldr, flags, alpha, tiles_m, tps, split_stride);
+  // tps / kt_per_split are in units of 64-deep K tiles at the call sites; rescale for 32-deep kernels
+  hipLaunchKernelGGL((gemm_nt_kernel<STAGING, NST, TBN, MINB, TBK, NW>), grid, block, shmem, stream, (const bf16_t*)g.A,
+                     (const bf16_t*)g.B, g.C, g.bias, g.residual, g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.ldr, g.flags,
+                     g.alpha, tiles_m, g.tps * (64 / TBK), g.split_stride);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
 
-// 128-wide N tiles when they already give >= ~1.75 resident blocks per CU, else 64-wide
-static inline bool use_narrow(int M, int N) {
-  const long tiles128 = (long)((M + BM - 1) / BM) * ((N + 127) / 128);
-  return tiles128 < 448;
+static int dispatch(const GemmArgs& g, hipStream_t stream) {
+  int variant = (g.flags >> MH_GEMM_VARIANT_SHIFT) & 15;
+  if (g.flags & MH_GEMM_REGSTAGE) return launch_gemm<1, 2, 128, 2>(g, stream);
+  if (variant == 0) variant = 1;   // measured best on every shape of the step (profiles/r01_gemm_variants.md)
+  switch (variant) {
+    case 1: return launch_gemm<0, 2, 128, 2>(g, stream);   // 64 KiB, 2 blocks/CU
+    case 2: return launch_gemm<0, 4, 128, 1>(g, stream);   // 128 KiB, 1 block/CU, 3 tiles in flight
+    case 3: return launch_gemm<0, 3, 64, 2>(g, stream);    // 72 KiB, 2 blocks/CU, 2 tiles in flight each
+    case 4: return launch_gemm<0, 2, 64, 3>(g, stream);    // 48 KiB, 3 blocks/CU
+    case 5: return launch_gemm<0, 3, 128, 1>(g, stream);   // 96 KiB, 1 block/CU
+    case 6: return launch_gemm<0, 2, 128, 4, 32>(g, stream);   // BK=32: 32 KiB, 4 blocks/CU
+    case 7: return launch_gemm<0, 3, 128, 3, 32>(g, stream);   // BK=32: 48 KiB, 3 blocks/CU, 2 tiles in flight
+    case 8: return launch_gemm<0, 4, 128, 2, 32>(g, stream);   // BK=32: 64 KiB, 2 blocks/CU, 3 tiles in flight
+    case 9: return launch_gemm<0, 2, 128, 2, 64, 8>(g, stream);   // 8 waves/block (wave tile 32x64), 2 blocks/CU
+    case 10: return launch_gemm<0, 4, 128, 1, 64, 8>(g, stream);  // 8 waves/block, 4-deep ring, 1 block/CU
+    default: return MH_ERR_ARG;
+  }
+}
+
+// ---- split-K: partial fp32 slabs ws[splits][M][N], then a fixed-order reduction that applies the epilogue ----
+// Used (a) for skinny wgrad outputs with a huge reduction and (b) automatically for shapes whose 128x128 tile
+// count leaves the 256 CUs under-filled (N = 4096 dgrad / down-proj at M ~ 1.2k: 320 tiles; ViT N = 1408: 187 tiles):
+// measured cold-weight gains +9..25 % including the reduce pass (profiles/r01_gemm_splitk.md).
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, void* __restrict__ outv, const float* __restrict__ bias,
+                                     const float* res, int M, int N, int ldc, int ldr, int splits, int flags,
+                                     float alpha) {
+  const long total4 = (long)M * N / 4;
+  const long slab = (long)M * N;
+  const bool out_f32 = flags & MH_GEMM_OUT_F32;
+  const bool do_gelu = flags & MH_GEMM_GELU;
+  for (long i4 = blockIdx.x * (long)blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
+    const long i = i4 * 4;
+    float4_t s = *reinterpret_cast<const float4_t*>(ws + i);
+    for (int k = 1; k < splits; ++k) {
+      const float4_t p = *reinterpret_cast<const float4_t*>(ws + (long)k * slab + i);
+      s[0] += p[0]; s[1] += p[1]; s[2] += p[2]; s[3] += p[3];
+    }
+    const long m = i / N;
+    const int n = (int)(i - m * N);
+    float v[4] = {s[0] * alpha, s[1] * alpha, s[2] * alpha, s[3] * alpha};
+    if (bias) {
+      const float4_t b4 = *reinterpret_cast<const float4_t*>(bias + n);
+      v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+    }
+    if (do_gelu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+    }
+    if (res) {
+      const float4_t r4 = *reinterpret_cast<const float4_t*>(res + m * ldr + n);
+      v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
+    }
+    if (out_f32) {
+      *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(outv) + m * ldc + n) = (float4_t){v[0], v[1], v[2], v[3]};
+    } else {
+      uint2 pk;
+      pk.x = pack_bf2(v[0], v[1]);
+      pk.y = pack_bf2(v[2], v[3]);
+      *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(outv) + m * ldc + n) = pk;
+    }
+  }
+}
+
+static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t stream) {
+  const int nt = g0.K / 64;
+  if (splits > nt) splits = nt;
+  const int tps = (nt + splits - 1) / splits;
+  splits = (nt + tps - 1) / tps;
+  GemmArgs g = g0;
+  g.C = (void*)ws; g.ldc = g0.N; g.bias = nullptr; g.residual = nullptr; g.ldr = 0;
+  g.flags = MH_GEMM_OUT_F32; g.alpha = 1.0f; g.splits = splits; g.tps = tps; g.split_stride = (long)g0.M * g0.N;
+  int rc = launch_gemm<0, 2, 128, 2>(g, stream);
+  if (rc) return rc;
+  long gsz = ((long)g0.M * g0.N / 4 + 255) / 256;
+  if (gsz > 4096) gsz = 4096;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)gsz), dim3(256), 0, stream, ws, g0.C, g0.bias, g0.residual, g0.M,
+                     g0.N, g0.ldc, g0.ldr, splits, g0.flags, g0.alpha);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// caller-provided scratch for the automatic split-K path (no hidden allocation): mh_set_workspace once per device
+static float* g_ws = nullptr;
+static size_t g_ws_bytes = 0;
+extern "C" int mh_set_workspace(void* ptr, long bytes) {
+  g_ws = (float*)ptr;
+  g_ws_bytes = ptr ? (size_t)bytes : 0;
+  return MH_OK;
+}
+
+static int auto_splits(int M, int N, int K) {
+  const long tiles = (long)((M + BM - 1) / BM) * ((N + 127) / 128);
+  const int kt = K / 64;
+  if (N % 4) return 1;
+  if (tiles >= 256 && tiles < 400 && kt >= 128) return 3;
+  if (tiles >= 128 && tiles < 256 && kt >= 64) return 2;
+  if (tiles < 64 && kt >= 48) return 4;
+  return 1;
 }
 
 extern "C" int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                                const float* bias, const float* residual, int ldr, int flags, float alpha,
                                hipStream_t stream) {
   if (M <= 0 || N <= 0) return MH_OK;
-  if (K <= 0 || (K % BK) != 0 || (lda % 8) != 0 || (ldb % 8) != 0) return MH_ERR_ARG;
+  if (K <= 0 || (K % 64) != 0 || (lda % 8) != 0 || (ldb % 8) != 0) return MH_ERR_ARG;
   if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)C & 15)) return MH_ERR_ARG;
   if ((ldc % 4) != 0 || (residual && (ldr % 4) != 0)) return MH_ERR_ARG;
-  const int nt = K / BK;
-  const bool narrow = use_narrow(M, N);
-  if (flags & MH_GEMM_REGSTAGE) {
-    return narrow ? launch_gemm<false, 64>(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, flags, alpha, 1, nt, 0L, stream)
-                  : launch_gemm<false, 128>(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, flags, alpha, 1, nt, 0L, stream);
+  GemmArgs g = {A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, flags, alpha, 1, K / 64, 0L};
+  const int variant = (flags >> MH_GEMM_VARIANT_SHIFT) & 15;
+  if (variant == 0 && !(flags & MH_GEMM_REGSTAGE) && g_ws) {
+    const int s = auto_splits(M, N, K);
+    // the reduce reads `residual` and writes C element-wise, so C may alias residual (in-place accumulate)
+    if (s > 1 && (size_t)s * M * N * sizeof(float) <= g_ws_bytes) return run_splitk(g, s, g_ws, stream);
   }
-  return narrow ? launch_gemm<true, 64>(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, flags, alpha, 1, nt, 0L, stream)
-                : launch_gemm<true, 128>(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, flags, alpha, 1, nt, 0L, stream);
+  return dispatch(g, stream);
 }
 
-// ---- split-K variant for skinny outputs with a long reduction (wgrad of the conv stem, M,N small, K huge) ----
-// partial slabs ws[splits][M][N] fp32, then a fixed-order reduction -> deterministic.
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ out, int M, int N, int ldc,
-                                     int splits) {
-  const long total = (long)M * N;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += ws[(long)k * total + i];
-    out[(i / N) * ldc + (i % N)] = s;
-  }
-}
-
+// ---- explicit split-K entry (wgrad of the conv stem: M,N small, K huge); caller passes the scratch ----
 extern "C" long mh_gemm_splitk_ws_floats(int M, int N, int splits) { return (long)M * N * splits; }
 
 extern "C" int mh_gemm_bf16_nt_splitk(const void* A, int lda, const void* B, int ldb, float* C, int ldc, int M, int N,
                                       int K, int splits, float* ws, hipStream_t stream) {
   if (M <= 0 || N <= 0) return MH_OK;
-  if (K <= 0 || (K % BK) != 0 || (lda % 8) != 0 || (ldb % 8) != 0 || (N % 4) != 0 || splits < 1) return MH_ERR_ARG;
-  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)ws & 15)) return MH_ERR_ARG;
-  const int nt = K / BK;
-  if (splits > nt) splits = nt;
-  const int tps = (nt + splits - 1) / splits;
-  splits = (nt + tps - 1) / tps;
-  int rc = launch_gemm<true, 128>(A, lda, B, ldb, (void*)ws, N, M, N, K, nullptr, nullptr, 0, MH_GEMM_OUT_F32, 1.0f, splits,
-                                  tps, (long)M * N, stream);
-  if (rc) return rc;
-  long g = ((long)M * N + 255) / 256;
-  if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)g), dim3(256), 0, stream, ws, C, M, N, ldc, splits);
-  MH_CHECK_LAUNCH();
-  return MH_OK;
+  if (K <= 0 || (K % 64) != 0 || (lda % 8) != 0 || (ldb % 8) != 0 || (N % 4) != 0 || (ldc % 4) != 0 || splits < 1)
+    return MH_ERR_ARG;
+  if (((uintptr_t)A & 15) || ((uintptr_t)B & 15) || ((uintptr_t)ws & 15) || ((uintptr_t)C & 15)) return MH_ERR_ARG;
+  GemmArgs g = {A, lda, B, ldb, (void*)C, ldc, M, N, K, nullptr, nullptr, 0, MH_GEMM_OUT_F32, 1.0f, 1, K / 64, 0L};
+  return run_splitk(g, splits, ws, stream);
 }

@@ -118,6 +118,7 @@ class MyriadHIP(nn.Module):
         self.llama_tokenizer = cfg.get("tokenizer", None)
         self.prompt_list = cfg.get("prompt_list", [])
         need_bwd = cfg.get("need_backward", True)
+        ops.ensure_workspace(self._dev)                        # scratch for the automatic split-K GEMM path
         self.visual_encoder = EvaViTHIP(weights, cfg.get("vit_heads", 16), self._dev)
         self.qformer = QFormerHIP(weights, cfg.get("qf_heads", 12), self._dev,
                                   need_backward=need_bwd and self.arch == "myriad")

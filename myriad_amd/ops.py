@@ -15,6 +15,7 @@ F32 = torch.float32
 GEMM_OUT_F32 = 1
 GEMM_GELU = 2
 GEMM_REGSTAGE = 4
+GEMM_VARIANT = 0      # 0 = library default; 1..5 force a kernel variant (tools/gemm_bench.py A/B tests)
 
 
 def _L():
@@ -35,6 +36,19 @@ def _chk2d(t: torch.Tensor, dtype, name: str):
                                   f"{t.dtype} {tuple(t.shape)} strides {t.stride()} cuda={t.is_cuda}")
 
 
+_WS = {}
+
+
+def ensure_workspace(device, nbytes: int = 256 << 20):
+    """Register a split-K scratch buffer with the library (once per device)."""
+    key = str(device)
+    if key not in _WS:
+        buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+        _lib.check(_L().mh_set_workspace(buf.data_ptr(), nbytes), "mh_set_workspace")
+        _WS[key] = buf
+    return _WS[key]
+
+
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -42,7 +56,7 @@ def round_up(x: int, m: int) -> int:
 # --------------------------------------------------------------------------- GEMM
 def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
          residual: Optional[torch.Tensor] = None, out_dtype=BF16, gelu: bool = False, alpha: float = 1.0,
-         regstage: bool = False) -> torch.Tensor:
+         regstage: bool = False, variant: int = -1) -> torch.Tensor:
     """out[M,N] = alpha * a[M,K] @ b[N,K]^T (+bias) (gelu) (+residual f32)."""
     _chk2d(a, BF16, "gemm.a")
     _chk2d(b, BF16, "gemm.b")
@@ -57,6 +71,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, b
         if out.shape != (M, N):
             raise _lib.MyriadHipError(f"gemm: out shape {tuple(out.shape)} != {(M, N)}")
     flags = (GEMM_OUT_F32 if out.dtype == F32 else 0) | (GEMM_GELU if gelu else 0) | (GEMM_REGSTAGE if regstage else 0)
+    flags |= (GEMM_VARIANT if variant < 0 else variant) << 8
     if bias is not None and (bias.dtype != F32 or bias.numel() != N):
         raise _lib.MyriadHipError("gemm: bias must be f32 [N]")
     ldr = 0

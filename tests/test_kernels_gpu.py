@@ -83,6 +83,27 @@ def test_gemm_splitk_wgrad_shapes(M, N, K):
     assert relerr(wide[:, 4:4 + N], ref) < 1e-4 and wide[:, :4].abs().max() == 0
 
 
+@pytest.mark.parametrize("M,N,K", [(1184, 4096, 11008), (2056, 1408, 6144), (648, 768, 3072)])
+def test_gemm_auto_splitk_epilogue(M, N, K):
+    """With a registered workspace mh_gemm_bf16_nt splits K for under-filled shapes; the epilogue moves into the
+    reduce pass and must give the same results (bias + GELU + residual, bf16 and f32 out, in-place accumulate)."""
+    ops.ensure_workspace(DEV)
+    a = bf(rnd(M, K, seed=9)).to(DEV)
+    b = bf(rnd(N, K, seed=10) * 0.05).to(DEV)
+    bias = rnd(N, seed=11).to(DEV)
+    res = rnd(M, N, seed=12).to(DEV)
+    ref = a.float() @ b.float().T
+    o = ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32)
+    assert relerr(o, ref + bias + res) < 1e-4
+    o_plain = ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32, variant=1)   # forced single-pass kernel
+    assert relerr(o, o_plain) < 1e-5
+    ob = ops.gemm(a, b, bias=bias, gelu=True)
+    assert relerr(ob.float(), F.gelu(ref + bias)) < 6e-3
+    acc = res.clone()
+    ops.gemm(a, b, out=acc, residual=acc)
+    assert relerr(acc, ref + res) < 1e-4
+
+
 def test_gemm_rejects_bad_k():
     a = bf(rnd(8, 40)).to(DEV)
     b = bf(rnd(8, 40)).to(DEV)

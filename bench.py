@@ -177,6 +177,7 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="per-GPU images per step (reference: 4 + 4 augmented)")
     ap.add_argument("--arch", default="myriad", choices=["myriad", "mini_gpt4"])
     ap.add_argument("--stage", type=int, default=1)
+    ap.add_argument("--lora", type=int, default=1, help="PEFT LoRA r=8 on q_proj/v_proj (BASELINE metric: Vicuna-7B+LoRA)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--llm-layers", type=int, default=32)
@@ -204,7 +205,7 @@ def main():
     cls = MyriadHIP if a.arch == "myriad" else MiniGPT4HIP
     t0 = time.time()
     model = cls(weights, dict(fixed_stage=a.stage, fixed_taskstage=0, vit_heads=cfg["vit_heads"], qf_heads=cfg["qf_heads"],
-                              llm_heads=cfg["llm_heads"]), device=dev)
+                              llm_heads=cfg["llm_heads"], use_lora=bool(a.lora) and a.arch == "myriad"), device=dev)
     torch.cuda.synchronize()
     build_s = time.time() - t0
     dp = DataParallel(dev)
@@ -276,6 +277,7 @@ def main():
                                    f"224x224 image, 32-token prompt, 16-token target, S={fl['S']}",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "seq_len": fl["S"],
                        "parallelism": f"dp{world}", "trainable_params": model.store.n_params(),
+                       "peft_lora_qv_r8": bool(a.lora) and a.arch == "myriad",
                        "algorithmic_tflop_per_sample": round(fl["total"] / 1e12, 3)},
             "loss": round(float(loss), 4), "model_build_s": round(build_s, 1),
         }

@@ -60,7 +60,7 @@ int mh_attn_bwd(const void* q, const void* k, const void* v, const void* o, cons
 
 /* K7 RMSNorm (modeling_llama.py:66-74) f32 in -> bf16 out; bwd is dgrad-only (+ optional residual-grad add,
  * optional bf16 copy of dx for the next dgrad GEMM). */
-int mh_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, int M, int D, float eps, mh_stream_t s);
+int mh_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, long ldy, int M, int D, float eps, mh_stream_t s);
 int mh_rmsnorm_bwd(const float* dy, const float* x, const float* w, const float* dres, float* dx, void* dx_bf16,
                    int M, int D, float eps, mh_stream_t s);
 /* K6 LayerNorm (eva_vit.py:175-176; blip2.py:119-125; Qformer.py:106,288,374) f32 in -> bf16 and/or f32 out. */
@@ -79,6 +79,26 @@ int mh_silu_mul_bwd(const void* dh, const void* gu, void* dgu, int M, int I, mh_
 /* erf-GELU on bf16 (Qformer.py:352-356 via ACT2FN["gelu"]) */
 int mh_gelu_fwd(const void* x, void* y, long n, mh_stream_t s);
 int mh_gelu_bwd(const void* dy, const void* x, void* dx, long n, mh_stream_t s);
+
+/* counter-based dropout for PEFT lora_dropout (myriad.py:171-178): mask = f(seed, flat index); bwd regenerates it */
+int mh_dropout_bf16(const void* x, long ldx, void* y, long ldy, long rows, int cols, float p, unsigned long long seed,
+                    mh_stream_t s);
+int mh_dropout_add_f32(const float* dy, long lddy, float* acc, long ldacc, long rows, int cols, float p,
+                       unsigned long long seed, mh_stream_t s);
+
+/* K10 (PEFT form) LoRA on q_proj/v_proj, y = W x + (alpha/r) B (A dropout(x)) (myriad.py:170-180).  The UP projection
+ * rides the qkv GEMM as a 64-column K border; these kernels do the skinny parts.  A = [R2, D] f32 (A_q rows then A_v
+ * rows, R2 = 2r in {16,32}); border / dborder = columns [D, D+R2) of the bordered operand / its gradient. */
+int mh_lora_down(const void* x, long ldx, const float* A, void* border, long ldo, int M, int D, int R2, float s, float p,
+                 unsigned long long seed, mh_stream_t st);
+int mh_lora_dx(const float* dx_ext, long ld, const float* A, float* out, int M, int D, int R2, float s, float p,
+               unsigned long long seed, mh_stream_t st);
+long mh_lora_wgrad_ws_floats(int D, int R2);
+int mh_lora_wgrad(const void* x, long ldx, const float* dx_ext, long ldg, const void* dq, const void* dv, long ldq,
+                  const void* border, long ldb, float* dA, float* dBq, float* dBv, float* ws, int M, int D, int R2,
+                  float s, float p, unsigned long long seed, mh_stream_t st);
+int mh_lora_refresh_border(const float* Bq, const float* Bv, void* ext, long ld_ext, void* extT, long ld_extT, int W,
+                           int D, int r, mh_stream_t st);
 
 /* K10 rank-r adaptor y = x + (x A^T) B^T (networks.py:81-93), f32, r in {1,2,4,8}. */
 int mh_lowrank_fwd(const float* x, const float* A, const float* Bm, float* y, float* t, int M, int D, int R,

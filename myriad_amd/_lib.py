@@ -11,7 +11,8 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG, "libmyriad_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "myriad_hip.h")
 
-_CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double}
+_CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
+       "unsigned long long": ctypes.c_ulonglong}
 
 
 class MyriadHipError(RuntimeError):
@@ -33,7 +34,8 @@ def parse_header(path: str = HEADER_PATH) -> Dict[str, Tuple[object, List[object
                 if "*" in a or a.startswith("mh_stream_t"):
                     argtypes.append(ctypes.c_void_p)
                 else:
-                    base = a.replace("const ", "").split()[0]
+                    toks = a.replace("const ", "").split()
+                    base = " ".join(toks[:-1]) if len(toks) > 1 else toks[0]
                     argtypes.append(_CT[base])
         out[name] = (restype, argtypes)
     return out

@@ -455,3 +455,63 @@ extern "C" int mh_patchify_nchw(const float* img, void* out, int B, int C, int H
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
+
+// ---- counter-based dropout (PEFT lora_dropout, reference myriad.py:171-178): keep-mask = hash(seed, index) >= p ----
+// The mask is a pure function of (seed, flat element index), so backward regenerates it instead of storing it.
+__device__ __forceinline__ float keep_scale(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+  unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = (float)(z >> 40) * (1.0f / 16777216.0f);   // 24-bit uniform in [0,1)
+  return u >= p ? inv_keep : 0.f;
+}
+// y[r][c] = x[r][c] * mask/(1-p), mask index = r*cols + c
+__global__ void dropout_bf16_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ y, long ldy, long rows,
+                                    int cols8, float p, unsigned long long seed) {
+  const float ik = 1.f / (1.f - p);
+  const long total = rows * cols8;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long r = it / cols8;
+    const int c = (int)(it - r * cols8) * 8;
+    const short8_t v = *reinterpret_cast<const short8_t*>(x + r * ldx + c);
+    short8_t o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e)
+      o[e] = (short)f2bf(bf2f((bf16_t)v[e]) * keep_scale(seed, (unsigned long long)(r * (long)cols8 * 8 + c + e), p, ik));
+    *reinterpret_cast<short8_t*>(y + r * ldy + c) = o;
+  }
+}
+// acc[r][c] += dy[r][c] * mask/(1-p), mask index = r*cols + c (contiguous index space of the forward tensor)
+__global__ void dropout_add_f32_kernel(const float* __restrict__ dy, long lddy, float* acc, long ldacc, long rows,
+                                       int cols4, float p, unsigned long long seed) {
+  const float ik = 1.f / (1.f - p);
+  const long total = rows * cols4;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long r = it / cols4;
+    const int c = (int)(it - r * cols4) * 4;
+    const float4_t g = *reinterpret_cast<const float4_t*>(dy + r * lddy + c);
+    float4_t a = *reinterpret_cast<const float4_t*>(acc + r * ldacc + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[e] += g[e] * keep_scale(seed, (unsigned long long)(r * (long)cols4 * 4 + c + e), p, ik);
+    *reinterpret_cast<float4_t*>(acc + r * ldacc + c) = a;
+  }
+}
+extern "C" int mh_dropout_bf16(const void* x, long ldx, void* y, long ldy, long rows, int cols, float p,
+                               unsigned long long seed, hipStream_t stream) {
+  if (rows <= 0 || cols <= 0) return MH_OK;
+  if (cols % 8 || ldx % 8 || ldy % 8 || p < 0.f || p >= 1.f) return MH_ERR_ARG;
+  hipLaunchKernelGGL(dropout_bf16_kernel, dim3(ew_grid(rows * (cols / 8))), dim3(EW_NT), 0, stream, (const bf16_t*)x, ldx,
+                     (bf16_t*)y, ldy, rows, cols / 8, p, seed);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+extern "C" int mh_dropout_add_f32(const float* dy, long lddy, float* acc, long ldacc, long rows, int cols, float p,
+                                  unsigned long long seed, hipStream_t stream) {
+  if (rows <= 0 || cols <= 0) return MH_OK;
+  if (cols % 4 || lddy % 4 || ldacc % 4 || p < 0.f || p >= 1.f) return MH_ERR_ARG;
+  hipLaunchKernelGGL(dropout_add_f32_kernel, dim3(ew_grid(rows * (cols / 4))), dim3(EW_NT), 0, stream, dy, lddy, acc, ldacc,
+                     rows, cols / 4, p, seed);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}

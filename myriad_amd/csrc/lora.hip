@@ -1,0 +1,221 @@
+// K10 (PEFT form): LoRA on q_proj / v_proj,  y = W x + (alpha/r) B (A dropout(x))   (reference myriad.py:170-180;
+// arithmetic = the published peft LoRA layer).  The rank-r UP projection rides the qkv MFMA GEMM as a 64-column K
+// border (myriad_amd/lora.py); these wavefront-primitive kernels do the skinny parts without materialising the
+// dropout mask, transposes or [M,4096] temporaries:
+//   lora_down : border[m, j] = s * sum_d keep(m,d) x[m,d] A[j,d]                  (block-per-row reductions)
+//   lora_dx   : dxn[m,d] = dx_base[m,d] + keep(m,d) * s * sum_j dborder[m,j] A[j,d]   (elementwise, A from L2)
+//   lora_wgrad: dA[j,d] = sum_m s dborder[m,j] keep(m,d) x[m,d] ; dB_q[d,j] = sum_m dq[m,d] border[m,j] ; dB_v likewise
+//               (thread-per-column partial sums over row chunks + fixed-order reduce: deterministic)
+//   lora_refresh_border: writes bf16(B_q), bf16(B_v) into the borders of W_ext and W_ext^T.
+// keep(m,d) = hash(seed, m*D+d) >= p ? 1/(1-p) : 0  -- regenerated, never stored.  R2 = 2r (q then v), r in {8,16}.
+#include "common.h"
+
+#define LR_NT 256
+#define LR_NW 4
+#define LR_CH 16   // row chunks of the wgrad partial sums
+
+__device__ __forceinline__ float lora_keep(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+  if (p <= 0.f) return 1.f;
+  unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z ^= z >> 31;
+  const float u = (float)(z >> 40) * (1.0f / 16777216.0f);
+  return u >= p ? inv_keep : 0.f;
+}
+
+template <int R2>
+__global__ __launch_bounds__(LR_NT) void lora_down_kernel(const bf16_t* __restrict__ x, long ldx,
+                                                          const float* __restrict__ A, bf16_t* __restrict__ out, long ldo,
+                                                          int D, float s, float p, unsigned long long seed) {
+  __shared__ float red[LR_NW];
+  const long m = blockIdx.x;
+  const float ik = 1.f / (1.f - p);
+  float part[R2];
+#pragma unroll
+  for (int j = 0; j < R2; ++j) part[j] = 0.f;
+  for (int d = threadIdx.x * 4; d < D; d += LR_NT * 4) {
+    const short4_t v = *reinterpret_cast<const short4_t*>(x + m * ldx + d);
+    float xv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) xv[e] = bf2f((bf16_t)v[e]) * lora_keep(seed, (unsigned long long)(m * D + d + e), p, ik);
+#pragma unroll
+    for (int j = 0; j < R2; ++j) {
+      const float4_t a = *reinterpret_cast<const float4_t*>(A + (long)j * D + d);
+      part[j] += xv[0] * a[0] + xv[1] * a[1] + xv[2] * a[2] + xv[3] * a[3];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < R2; ++j) {
+    const float t = block_sum<LR_NW>(part[j], red);
+    if (threadIdx.x == 0) out[m * ldo + j] = f2bf(s * t);
+  }
+}
+
+template <int R2>
+__global__ void lora_dx_kernel(const float* __restrict__ dx_ext, long ld, const float* __restrict__ A,
+                               float* __restrict__ out, long M, int D, float s, float p, unsigned long long seed) {
+  const float ik = 1.f / (1.f - p);
+  const int per_row = D >> 2;
+  const long total = M * per_row;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long m = it / per_row;
+    const int d = (int)(it - m * per_row) * 4;
+    const float* row = dx_ext + m * ld;
+    float4_t acc = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < R2; ++j) {
+      const float g = row[D + j];
+      const float4_t a = *reinterpret_cast<const float4_t*>(A + (long)j * D + d);
+      acc[0] += g * a[0]; acc[1] += g * a[1]; acc[2] += g * a[2]; acc[3] += g * a[3];
+    }
+    const float4_t base = *reinterpret_cast<const float4_t*>(row + d);
+    float4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = base[e] + s * acc[e] * lora_keep(seed, (unsigned long long)(m * D + d + e), p, ik);
+    *reinterpret_cast<float4_t*>(out + m * D + d) = o;
+  }
+}
+
+// partial sums over a row chunk; one thread per column d
+template <int R2>
+__global__ __launch_bounds__(LR_NT) void lora_wgrad_partial_kernel(
+    const bf16_t* __restrict__ x, long ldx, const float* __restrict__ dx_ext, long ldg, const bf16_t* __restrict__ dq,
+    const bf16_t* __restrict__ dv, long ldq, const bf16_t* __restrict__ border, long ldb, float* __restrict__ pA,
+    float* __restrict__ pBq, float* __restrict__ pBv, int M, int D, float s, float p, unsigned long long seed) {
+  constexpr int r = R2 / 2;
+  __shared__ float sg[R2], st[R2];
+  const int d = blockIdx.x * LR_NT + threadIdx.x;
+  const int chunk = blockIdx.y;
+  const int rows_per = (M + LR_CH - 1) / LR_CH;
+  const int m0 = chunk * rows_per;
+  const int m1 = (m0 + rows_per) < M ? (m0 + rows_per) : M;
+  const float ik = 1.f / (1.f - p);
+  float a[R2], bq[r], bv[r];
+#pragma unroll
+  for (int j = 0; j < R2; ++j) a[j] = 0.f;
+#pragma unroll
+  for (int j = 0; j < r; ++j) { bq[j] = 0.f; bv[j] = 0.f; }
+  for (int m = m0; m < m1; ++m) {
+    __syncthreads();
+    if (threadIdx.x < R2) {
+      sg[threadIdx.x] = s * dx_ext[(long)m * ldg + D + threadIdx.x];
+      st[threadIdx.x] = bf2f(border[(long)m * ldb + threadIdx.x]);
+    }
+    __syncthreads();
+    if (d < D) {
+      const float xd = bf2f(x[(long)m * ldx + d]) * lora_keep(seed, (unsigned long long)((long)m * D + d), p, ik);
+      const float gq = bf2f(dq[(long)m * ldq + d]), gv = bf2f(dv[(long)m * ldq + d]);
+#pragma unroll
+      for (int j = 0; j < R2; ++j) a[j] += sg[j] * xd;
+#pragma unroll
+      for (int j = 0; j < r; ++j) {
+        bq[j] += gq * st[j];
+        bv[j] += gv * st[r + j];
+      }
+    }
+  }
+  if (d < D) {
+#pragma unroll
+    for (int j = 0; j < R2; ++j) pA[((long)chunk * R2 + j) * D + d] = a[j];
+#pragma unroll
+    for (int j = 0; j < r; ++j) {
+      pBq[((long)chunk * D + d) * r + j] = bq[j];
+      pBv[((long)chunk * D + d) * r + j] = bv[j];
+    }
+  }
+}
+__global__ void lora_wgrad_reduce_kernel(const float* __restrict__ pA, const float* __restrict__ pBq,
+                                         const float* __restrict__ pBv, float* __restrict__ dA, float* __restrict__ dBq,
+                                         float* __restrict__ dBv, int nA, int nB) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < nA) {
+    float s = 0.f;
+    for (int c = 0; c < LR_CH; ++c) s += pA[(long)c * nA + i];
+    dA[i] = s;
+  }
+  if (i < nB) {
+    float s = 0.f, t = 0.f;
+    for (int c = 0; c < LR_CH; ++c) {
+      s += pBq[(long)c * nB + i];
+      t += pBv[(long)c * nB + i];
+    }
+    dBq[i] = s;
+    dBv[i] = t;
+  }
+}
+
+__global__ void lora_refresh_kernel(const float* __restrict__ Bq, const float* __restrict__ Bv, bf16_t* __restrict__ ext,
+                                    long ld_ext, bf16_t* __restrict__ extT, long ld_extT, int W, int D, int r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // i = n*r + j
+  if (i >= W * r) return;
+  const int n = i / r, j = i - n * r;
+  const bf16_t q = f2bf(Bq[i]), v = f2bf(Bv[i]);
+  ext[(long)n * ld_ext + D + j] = q;
+  ext[(long)(2 * W + n) * ld_ext + D + r + j] = v;
+  if (extT) {   // absent when the model was built without backward support (inference)
+    extT[(long)(D + j) * ld_extT + n] = q;
+    extT[(long)(D + r + j) * ld_extT + 2 * W + n] = v;
+  }
+}
+
+#define LORA_DISPATCH(R2_, CALL)                      \
+  switch (R2_) {                                      \
+    case 16: { constexpr int R2 = 16; CALL; break; }  \
+    case 32: { constexpr int R2 = 32; CALL; break; }  \
+    default: return MH_ERR_UNSUPPORTED;               \
+  }
+
+extern "C" int mh_lora_down(const void* x, long ldx, const float* A, void* border, long ldo, int M, int D, int R2_,
+                            float s, float p, unsigned long long seed, hipStream_t stream) {
+  if (M <= 0) return MH_OK;
+  if (D % 4 || ldx % 4 || p < 0.f || p >= 1.f) return MH_ERR_ARG;
+  LORA_DISPATCH(R2_, hipLaunchKernelGGL(lora_down_kernel<R2>, dim3(M), dim3(LR_NT), 0, stream, (const bf16_t*)x, ldx, A,
+                                        (bf16_t*)border, ldo, D, s, p, seed));
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_lora_dx(const float* dx_ext, long ld, const float* A, float* out, int M, int D, int R2_, float s,
+                          float p, unsigned long long seed, hipStream_t stream) {
+  if (M <= 0) return MH_OK;
+  if (D % 4 || ld % 4 || ld < D + R2_ || p < 0.f || p >= 1.f) return MH_ERR_ARG;
+  long g = ((long)M * (D / 4) + 255) / 256;
+  if (g > 4096) g = 4096;
+  LORA_DISPATCH(R2_, hipLaunchKernelGGL(lora_dx_kernel<R2>, dim3((int)g), dim3(256), 0, stream, dx_ext, ld, A, out, (long)M,
+                                        D, s, p, seed));
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" long mh_lora_wgrad_ws_floats(int D, int R2_) { return (long)LR_CH * (2L * R2_ * D); }
+
+extern "C" int mh_lora_wgrad(const void* x, long ldx, const float* dx_ext, long ldg, const void* dq, const void* dv,
+                             long ldq, const void* border, long ldb, float* dA, float* dBq, float* dBv, float* ws, int M,
+                             int D, int R2_, float s, float p, unsigned long long seed, hipStream_t stream) {
+  if (M <= 0) return MH_OK;
+  if (p < 0.f || p >= 1.f) return MH_ERR_ARG;
+  const int r = R2_ / 2;
+  float* pA = ws;
+  float* pBq = pA + (long)LR_CH * R2_ * D;
+  float* pBv = pBq + (long)LR_CH * D * r;
+  const dim3 grid((D + LR_NT - 1) / LR_NT, LR_CH);
+  LORA_DISPATCH(R2_, hipLaunchKernelGGL(lora_wgrad_partial_kernel<R2>, grid, dim3(LR_NT), 0, stream, (const bf16_t*)x, ldx,
+                                        dx_ext, ldg, (const bf16_t*)dq, (const bf16_t*)dv, ldq, (const bf16_t*)border, ldb,
+                                        pA, pBq, pBv, M, D, s, p, seed));
+  MH_CHECK_LAUNCH();
+  const int nA = R2_ * D, nB = D * r;
+  hipLaunchKernelGGL(lora_wgrad_reduce_kernel, dim3((nA + 255) / 256), dim3(256), 0, stream, pA, pBq, pBv, dA, dBq, dBv, nA,
+                     nB);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_lora_refresh_border(const float* Bq, const float* Bv, void* ext, long ld_ext, void* extT, long ld_extT,
+                                      int W, int D, int r, hipStream_t stream) {
+  const int n = W * r;
+  hipLaunchKernelGGL(lora_refresh_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, Bq, Bv, (bf16_t*)ext, ld_ext,
+                     (bf16_t*)extT, ld_extT, W, D, r);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}

@@ -11,7 +11,7 @@
 
 // ---- RMSNorm ---------------------------------------------------------------------------------
 __global__ __launch_bounds__(NT) void rmsnorm_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                         bf16_t* __restrict__ y, int D, float eps) {
+                                                         bf16_t* __restrict__ y, int D, long ldy, float eps) {
   __shared__ float red[NW];
   const size_t row = blockIdx.x;
   const float* xr = x + row * D;
@@ -28,7 +28,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_fwd_kernel(const float* __restrict
     uint2 pk;
     pk.x = pack_bf2(g[0] * (v[0] * r), g[1] * (v[1] * r));
     pk.y = pack_bf2(g[2] * (v[2] * r), g[3] * (v[3] * r));
-    *reinterpret_cast<uint2*>(y + row * D + i) = pk;
+    *reinterpret_cast<uint2*>(y + row * ldy + i) = pk;
   }
 }
 
@@ -171,11 +171,11 @@ __global__ __launch_bounds__(NT) void layernorm_bwd_kernel(const float* __restri
   }
 }
 
-extern "C" int mh_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, int M, int D, float eps,
+extern "C" int mh_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, long ldy, int M, int D, float eps,
                               hipStream_t stream) {
   if (M <= 0) return MH_OK;
-  if (D % 4) return MH_ERR_ARG;
-  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(M), dim3(NT), 0, stream, x, w, (bf16_t*)y_bf16, D, eps);
+  if (D % 4 || ldy % 4 || ldy < D) return MH_ERR_ARG;
+  hipLaunchKernelGGL(rmsnorm_fwd_kernel, dim3(M), dim3(NT), 0, stream, x, w, (bf16_t*)y_bf16, D, ldy, eps);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

@@ -78,6 +78,13 @@ class LlamaHIP:
         self.cos = fr.cos().contiguous().to(self.dev)
         self.sin = fr.sin().contiguous().to(self.dev)
         self._saved = None
+        self.lora = None
+
+    def attach_lora(self, lora) -> None:
+        """Enable PEFT-style LoRA on q_proj/v_proj (myriad_amd.lora.LoraQV); replaces W_qkv by its bordered copy."""
+        for L in self.layers:
+            lora.extend_weights(L)
+        self.lora = lora
 
     # ------------------------------------------------------------------ training forward
     def forward_loss(self, x: torch.Tensor, attention_mask: torch.Tensor, labels: torch.Tensor,
@@ -96,9 +103,20 @@ class LlamaHIP:
         scale = 1.0 / math.sqrt(hd)
         h = x.reshape(M, D)
         saved = []
-        for L in self.layers:
-            xn = ops.rmsnorm_fwd(h, L["ln1"], self.eps)
-            qkv = ops.gemm(xn, L["wqkv"])                                   # [M, 3W] bf16
+        lora = self.lora
+        if lora is not None:
+            lora.refresh(self.layers)
+        for li, L in enumerate(self.layers):
+            lsave = None
+            if lora is None:
+                xn = ops.rmsnorm_fwd(h, L["ln1"], self.eps)
+                qkv = ops.gemm(xn, L["wqkv"])                               # [M, 3W] bf16
+            else:   # q/v LoRA rides the qkv GEMM as a 64-column K border (myriad_amd/lora.py)
+                x_ext = lora.x_ext(li, M)
+                ops.rmsnorm_fwd(h, L["ln1"], self.eps, out=x_ext[:, :D])
+                p_eff, seed = lora.forward_border(li, x_ext)
+                qkv = ops.gemm(x_ext, L["wqkv_ext"])
+                lsave = (x_ext, p_eff, seed)
             ops.rope_(qkv, 0, 2 * H, hd, pos, self.cos, self.sin, 1.0)      # q and k heads
             q3 = qkv.view(B, S, 3 * W)
             o, lse = ops.attn_fwd(q3[:, :, :W], q3[:, :, W:2 * W], q3[:, :, 2 * W:], H, hd, scale, causal=True,
@@ -109,7 +127,7 @@ class LlamaHIP:
             act = ops.silu_mul_fwd(gu)
             h3 = ops.gemm(act, L["wd"], residual=h2, out_dtype=F32)
             if save_for_backward:
-                saved.append((h, qkv, o, lse, h2, gu))
+                saved.append((h, qkv, o, lse, h2, gu, lsave))
             h = h3
         # loss on label-bearing rows only: row (b,s) predicts labels[b,s+1]
         lab = labels.to("cpu")
@@ -146,7 +164,9 @@ class LlamaHIP:
         dh = torch.zeros((M, D), dtype=F32, device=self.dev)
         ops.scatter_rows(dhr, sv["rows"], dh)
         dh_b = ops.to_bf16(dh)
-        for L, (h_in, qkv, o, lse, h2, gu) in zip(reversed(self.layers), reversed(sv["layers"])):
+        n_layers = len(self.layers)
+        for ri, (L, (h_in, qkv, o, lse, h2, gu, lsave)) in enumerate(zip(reversed(self.layers), reversed(sv["layers"]))):
+            li = n_layers - 1 - ri
             dact = ops.gemm(dh_b, L["wdT"])                                 # [M, I] bf16
             dgu = ops.silu_mul_bwd(dact, gu)
             dxn2 = ops.gemm(dgu, L["wguT"], out_dtype=F32)                  # [M, D]
@@ -159,7 +179,11 @@ class LlamaHIP:
                          sv["scale"], causal=True, kv_len=sv["kv_len"], dq=d3[:, :, :W], dk=d3[:, :, W:2 * W],
                          dv=d3[:, :, 2 * W:])
             ops.rope_(dqkv, 0, 2 * H, hd, sv["pos"], self.cos, self.sin, -1.0)
-            dxn = ops.gemm(dqkv, L["wqkvT"], out_dtype=F32)
+            if self.lora is None:
+                dxn = ops.gemm(dqkv, L["wqkvT"], out_dtype=F32)
+            else:
+                dx_ext = ops.gemm(dqkv, L["wqkvT_ext"], out_dtype=F32)      # [M, D+64]: base dgrad | d(s*t)
+                dxn = self.lora.backward(li, dx_ext, dqkv, lsave[0], lsave[1], lsave[2])
             dh, dh_b = ops.rmsnorm_bwd(dxn, h_in, L["ln1"], self.eps, dres=dh2, want_bf16=True)
         self._saved = None
         return dh.view(B, S, D)
@@ -185,9 +209,17 @@ class LlamaHIP:
             M = B * S
             pos = (torch.arange(S, dtype=torch.int32) + past).repeat(B).to(self.dev)
             h = x
-            for L, cache in zip(self.layers, caches):
-                xn = ops.rmsnorm_fwd(h, L["ln1"], self.eps)
-                qkv = ops.gemm(xn, L["wqkv"])
+            if self.lora is not None and step == 0:
+                self.lora.refresh(self.layers)
+            for li, (L, cache) in enumerate(zip(self.layers, caches)):
+                if self.lora is None:
+                    xn = ops.rmsnorm_fwd(h, L["ln1"], self.eps)
+                    qkv = ops.gemm(xn, L["wqkv"])
+                else:
+                    x_ext = self.lora.x_ext(li, M)
+                    ops.rmsnorm_fwd(h, L["ln1"], self.eps, out=x_ext[:, :D])
+                    self.lora.forward_border(li, x_ext, training=False)
+                    qkv = ops.gemm(x_ext, L["wqkv_ext"])
                 ops.rope_(qkv, 0, 2 * H, hd, pos, self.cos, self.sin, 1.0)
                 q3 = qkv.view(B, S, 3 * W)
                 ops.copy3d_bf16(q3[:, :, W:], cache[:, past:past + S])       # append k|v

@@ -1,0 +1,142 @@
+"""PEFT-style LoRA on q_proj / v_proj of the LLaMA decoder (reference minigpt4/models/myriad.py:170-180,198-200:
+LoraConfig(r=8, lora_alpha=16, lora_dropout=0.05, target_modules=["q_proj","v_proj"]); the arithmetic lives in the
+un-vendored `peft` package -- restated from its published form  y = W x + (alpha/r) * B(A(dropout(x))),
+A ~ kaiming-uniform, B = 0 at init.  SURVEY 8 a-14: parity unpinned by the reference, pinned here to the oracle.)
+
+MI355X formulation -- the rank-r UP projection rides the main MFMA GEMMs as a K-border instead of separate kernels:
+
+    forward   [ x | s*t ] . [ W_qkv | B_ext ]^T          t = dropout(x) A_qv^T        (K = 4096 + 64)
+    backward  dqkv . [ W_qkv | B_ext ]  ->  [ dx_base | d(s*t) ]   in ONE dgrad GEMM
+
+so q/k/v are rounded to bf16 once and no extra pass over the [B*S, 12288] qkv buffer is needed; the skinny parts
+(lora-down, dx correction, dA/dB) are wavefront-primitive kernels in csrc/lora.hip that regenerate the dropout mask
+from (seed, index) instead of storing it.  The 64-column border holds s*t_q (r) | s*t_v (r) | zeros.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Tuple
+
+import torch
+
+from . import _lib, ops
+
+BF16, F32 = torch.bfloat16, torch.float32
+BORDER = 64
+PEFT_PREFIX = "llama_model.base_model.model.model.layers."
+
+
+def lora_param_specs(n_layers: int, D: int, r: int) -> List[Tuple[str, Tuple[int, ...], Tuple[int, ...]]]:
+    """Reference (PEFT) state_dict names; per layer the order A_q, A_v, B_q, B_v keeps A_q|A_v contiguous."""
+    specs = []
+    for i in range(n_layers):
+        p = f"{PEFT_PREFIX}{i}.self_attn."
+        specs.append((p + "q_proj.lora_A.default.weight", (r, D), (r, D)))
+        specs.append((p + "v_proj.lora_A.default.weight", (r, D), (r, D)))
+        specs.append((p + "q_proj.lora_B.default.weight", (D, r), (D, r)))
+        specs.append((p + "v_proj.lora_B.default.weight", (D, r), (D, r)))
+    return specs
+
+
+def init_lora_weights(n_layers: int, D: int, r: int, seed: int, device, zero_b: bool = True) -> Dict[str, torch.Tensor]:
+    """peft init: lora_A kaiming_uniform(a=sqrt(5)) => U(-1/sqrt(D), 1/sqrt(D)); lora_B zeros."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    out = {}
+    bound = 1.0 / math.sqrt(D)
+    for name, ishape, _ in lora_param_specs(n_layers, D, r):
+        if "lora_A" in name:
+            out[name] = ((torch.rand(ishape, generator=g) * 2 - 1) * bound).to(device)
+        else:
+            out[name] = (torch.zeros(ishape) if zero_b else torch.randn(ishape, generator=g) * 0.02).to(device)
+    return out
+
+
+class LoraQV:
+    def __init__(self, n_layers: int, D: int, r: int, alpha: float, dropout: float, params: Dict[str, torch.Tensor],
+                 grads: Dict[str, torch.Tensor], device):
+        if r not in (8, 16):
+            raise ValueError("LoRA rank must be 8 or 16")
+        self.L, self.D, self.r, self.s, self.p = n_layers, D, r, alpha / r, dropout
+        self.dev = torch.device(device)
+        self.P, self.G = params, grads
+        self.step_seed = 0
+        self._xext: Dict[Tuple[int, int], torch.Tensor] = {}
+        self._ws = torch.empty((_lib.load().mh_lora_wgrad_ws_floats(D, 2 * r),), dtype=F32, device=self.dev)
+
+    def names(self, i):
+        p = f"{PEFT_PREFIX}{i}.self_attn."
+        return (p + "q_proj.lora_A.default.weight", p + "v_proj.lora_A.default.weight",
+                p + "q_proj.lora_B.default.weight", p + "v_proj.lora_B.default.weight")
+
+    def _aqv(self, store, i):
+        """[2r, D] fp32 view over the adjacent A_q | A_v segments of a flat buffer dict."""
+        aq, av = store[self.names(i)[0]], store[self.names(i)[1]]
+        assert av.data_ptr() == aq.data_ptr() + aq.numel() * 4, "A_q and A_v must be adjacent in the flat buffer"
+        return torch.as_strided(aq, (2 * self.r, self.D), (self.D, 1))
+
+    def extend_weights(self, layer: dict) -> None:
+        """Allocate the bordered copies of the frozen qkv weight (once)."""
+        W3, D = layer["wqkv"].shape
+        ext = torch.zeros((W3, D + BORDER), dtype=BF16, device=self.dev)
+        ext[:, :D].copy_(layer["wqkv"])
+        layer["wqkv_ext"] = ext
+        if layer.get("wqkvT") is not None:
+            extT = torch.zeros((D + BORDER, W3), dtype=BF16, device=self.dev)
+            extT[:D].copy_(layer["wqkvT"])
+            layer["wqkvT_ext"] = extT
+        layer["wqkv"] = layer["wqkvT"] = None     # the bordered copies replace them
+
+    def x_ext(self, layer_idx: int, M: int) -> torch.Tensor:
+        """Persistent bordered activation buffer [M, D+64] bf16 per layer (columns >= D+2r stay zero forever)."""
+        key = (layer_idx, M)
+        if key not in self._xext:
+            self._xext[key] = torch.zeros((M, self.D + BORDER), dtype=BF16, device=self.dev)
+        return self._xext[key]
+
+    def refresh(self, layers: List[dict]) -> None:
+        """Per optimisation step: push the current fp32 B_q / B_v into the bf16 borders of W_ext and W_ext^T."""
+        D, r, W = self.D, self.r, self.D
+        L = _lib.load()
+        s = ops._s()
+        for i, Lr in enumerate(layers):
+            _, _, nbq, nbv = self.names(i)
+            ext, extT = Lr["wqkv_ext"], Lr.get("wqkvT_ext")
+            _lib.check(L.mh_lora_refresh_border(self.P[nbq].data_ptr(), self.P[nbv].data_ptr(), ext.data_ptr(),
+                                                ext.stride(0), None if extT is None else extT.data_ptr(),
+                                                0 if extT is None else extT.stride(0), W, D, r, s),
+                       "mh_lora_refresh_border")
+
+    def _seed(self, layer_idx: int) -> int:
+        return (self.step_seed * 1315423911 + layer_idx * 2654435761 + 12345) & 0x7FFFFFFFFFFFFFFF
+
+    # ---- forward: border = s * dropout(x) A_qv^T ------------------------------------------------------------------
+    def forward_border(self, layer_idx: int, x_ext: torch.Tensor, training: bool = True):
+        D, r = self.D, self.r
+        p = self.p if training else 0.0
+        seed = self._seed(layer_idx)
+        A = self._aqv(self.P, layer_idx)
+        M = x_ext.shape[0]
+        _lib.check(_lib.load().mh_lora_down(x_ext.data_ptr(), x_ext.stride(0), A.data_ptr(), x_ext[:, D:].data_ptr(),
+                                            x_ext.stride(0), M, D, 2 * r, self.s, p, seed, ops._s()), "mh_lora_down")
+        return p, seed
+
+    # ---- backward ------------------------------------------------------------------------------------------------
+    def backward(self, layer_idx: int, dx_ext: torch.Tensor, dqkv: torch.Tensor, x_ext: torch.Tensor, p: float,
+                 seed: int) -> torch.Tensor:
+        """dx_ext [M, D+64] f32 = dqkv . [W | B_ext];  returns the full d(xn) [M, D] f32 (contiguous) and writes
+        dA_q, dA_v, dB_q, dB_v into the flat gradient buffer."""
+        D, r, W = self.D, self.r, self.D
+        M = dx_ext.shape[0]
+        _, _, nb_q, nb_v = self.names(layer_idx)
+        L = _lib.load()
+        A = self._aqv(self.P, layer_idx)
+        gA = self._aqv(self.G, layer_idx)
+        dv = dqkv[:, 2 * W:]
+        _lib.check(L.mh_lora_wgrad(x_ext.data_ptr(), x_ext.stride(0), dx_ext.data_ptr(), dx_ext.stride(0),
+                                   dqkv.data_ptr(), dv.data_ptr(), dqkv.stride(0), x_ext[:, D:].data_ptr(),
+                                   x_ext.stride(0), gA.data_ptr(), self.G[nb_q].data_ptr(), self.G[nb_v].data_ptr(),
+                                   self._ws.data_ptr(), M, D, 2 * r, self.s, p, seed, ops._s()), "mh_lora_wgrad")
+        dxn = torch.empty((M, D), dtype=F32, device=self.dev)
+        _lib.check(L.mh_lora_dx(dx_ext.data_ptr(), dx_ext.stride(0), A.data_ptr(), dxn.data_ptr(), M, D, 2 * r, self.s, p,
+                                seed, ops._s()), "mh_lora_dx")
+        return dxn

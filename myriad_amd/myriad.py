@@ -142,10 +142,23 @@ class MyriadHIP(nn.Module):
         else:
             specs.append(("llama_proj.weight", (self.Dl, self.Dq), (self.Dl, self.Dq)))
             specs.append(("llama_proj.bias", (self.Dl,), (self.Dl,)))
+        # PEFT LoRA on q_proj/v_proj (myriad.py:170-180): off in the shipped recipe, on with cfg use_lora
+        self.use_lora = bool(cfg.get("use_lora", False))
+        lora_init = {}
+        if self.use_lora:
+            from .lora import LoraQV, init_lora_weights, lora_param_specs
+            r = int(cfg.get("lora_r", 8))
+            n_l = len(self.llama.layers)
+            specs = lora_param_specs(n_l, self.Dl, r) + specs      # LoRA tensors first: keeps A_q|A_v adjacent
+            lora_init = init_lora_weights(n_l, self.Dl, r, seed=int(cfg.get("lora_seed", 1234)), device=self._dev)
         self.store = ParamStore(specs, self._dev)
         self._params = OrderedDict()
         for name, ishape, rshape in self.store.specs:
-            self.store.p[name].copy_(from_reference_layout(weights[name].to(self._dev, F32), ishape))
+            if name in lora_init and name not in weights:
+                src = lora_init[name]
+            else:
+                src = weights[name]
+            self.store.p[name].copy_(from_reference_layout(src.to(self._dev, F32), ishape))
             prm = nn.Parameter(self.store.p[name], requires_grad=True)
             prm.grad = self.store.g[name]
             self._params[name] = prm
@@ -154,6 +167,11 @@ class MyriadHIP(nn.Module):
             self.adaptor = LoraAdaptor(self.store.p, self.store.g)
             self.ve_tok = VENet("VETokenizer.", 5, self.Dl, self.store.p, self.store.g, self._dev)
             self.ve_ins = VENet("VEInstructor.", 1, self.Dq, self.store.p, self.store.g, self._dev)
+        if self.use_lora:
+            self.lora = LoraQV(len(self.llama.layers), self.Dl, int(cfg.get("lora_r", 8)),
+                               float(cfg.get("lora_alpha", 16)), float(cfg.get("lora_dropout", 0.05)),
+                               self.store.p, self.store.g, self._dev)
+            self.llama.attach_lora(self.lora)
         self._anchor = torch.zeros((), device=self._dev, requires_grad=True)
         self._ctx = None
 
@@ -208,7 +226,8 @@ class MyriadHIP(nn.Module):
         if weights is None:
             raise ValueError("cfg['weights'] is required (checkpoint state dict or SyntheticWeights)")
         keys = ("max_txt_len", "end_sym", "k_shot", "fixed_stage", "fixed_taskstage", "tokenizer", "prompt_list",
-                "vit_heads", "qf_heads", "llm_heads", "need_backward", "bos_token_id", "pad_token_id")
+                "vit_heads", "qf_heads", "llm_heads", "need_backward", "bos_token_id", "pad_token_id", "use_lora",
+                "lora_r", "lora_alpha", "lora_dropout", "lora_seed")
         sub = {k: get(k) for k in keys if get(k) is not None}
         model = cls(weights, sub, device=get("device", "cuda:0"))
         ckpt = get("ckpt", "")
@@ -310,6 +329,8 @@ class MyriadHIP(nn.Module):
         return emb, attn, labels, img_slices
 
     def _forward_impl(self, samples, need_grad: bool):
+        if self.use_lora:
+            self.lora.step_seed = (self.lora.step_seed + 1) if need_grad else self.lora.step_seed
         stage = self.fixed_stage if self.fixed_stage is not None else random.choice([0, 1, 2])   # myriad.py:378
         if self.arch != "myriad":
             stage = 0

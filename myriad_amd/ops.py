@@ -142,11 +142,28 @@ def attn_bwd(q, k, v, o, dout, lse, H: int, D: int, scale: float, causal: bool =
 
 # --------------------------------------------------------------------------- norms
 def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, out=None):
+    """out may be a [M, D] view of a wider bf16 buffer (row stride >= D)."""
     M, D = x.shape
     if out is None:
         out = torch.empty((M, D), dtype=BF16, device=x.device)
-    _lib.check(_L().mh_rmsnorm_fwd(_p(x), _p(w), _p(out), M, D, float(eps), _s()), "mh_rmsnorm_fwd")
+    _lib.check(_L().mh_rmsnorm_fwd(_p(x), _p(w), _p(out), out.stride(0), M, D, float(eps), _s()), "mh_rmsnorm_fwd")
     return out
+
+
+def dropout_bf16(x2d: torch.Tensor, p: float, seed: int):
+    """x2d: [rows, cols] bf16 (row stride free).  Returns a contiguous masked/rescaled copy."""
+    rows, cols = x2d.shape
+    y = torch.empty((rows, cols), dtype=BF16, device=x2d.device)
+    _lib.check(_L().mh_dropout_bf16(_p(x2d), x2d.stride(0), _p(y), cols, rows, cols, float(p),
+                                    int(seed) & 0xFFFFFFFFFFFFFFFF, _s()), "mh_dropout_bf16")
+    return y
+
+
+def dropout_add_(dy2d: torch.Tensor, acc2d: torch.Tensor, p: float, seed: int):
+    rows, cols = dy2d.shape
+    _lib.check(_L().mh_dropout_add_f32(_p(dy2d), dy2d.stride(0), _p(acc2d), acc2d.stride(0), rows, cols, float(p),
+                                       int(seed) & 0xFFFFFFFFFFFFFFFF, _s()), "mh_dropout_add_f32")
+    return acc2d
 
 
 def rmsnorm_bwd(dy, x, w, eps: float, dres=None, want_f32=True, want_bf16=False):

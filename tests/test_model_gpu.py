@@ -299,3 +299,51 @@ def test_ve_net_grads_vs_bf16_forward_emulation():
         got = st.g[f"VEInstructor.meta_net.{idx}.weight"]
         assert cos_sim(got, want) > 0.995 and relerr(got, want) < 6e-2, (idx, cos_sim(got, want), relerr(got, want))
         assert relerr(st.g[f"VEInstructor.meta_net.{idx}.bias"], prm[f"VEInstructor.meta_net.{idx}.bias"].grad) < 6e-2, idx
+
+
+# ------------------------------------------------------------------------------------------------ PEFT LoRA (a-14)
+@pytest.mark.parametrize("dropout", [0.0, 0.05])
+def test_llama_lora_qv_vs_oracle(dropout):
+    """q/v LoRA as a K-border of the qkv GEMM vs the oracle's restated peft formula (parity unpinned by the
+    reference: peft is un-vendored).  With dropout the oracle is fed the HIP path's own keep-mask."""
+    from myriad_amd.lora import LoraQV, PEFT_PREFIX, lora_param_specs
+    from myriad_amd.myriad import ParamStore
+    D, layers, heads, inter, V, r = 4096, 1, 32, 11008, 1000, 8
+    sd = gu.llama_weights(D, layers, inter, V, seed=611)
+    gen = torch.Generator().manual_seed(612)
+    lora_sd = {}
+    for name, ishape, _ in lora_param_specs(layers, D, r):
+        lora_sd[name] = torch.randn(ishape, generator=gen) * (0.02 if "lora_A" in name else 0.05)
+    emb = torch.randn(2, 24, D, generator=gen) * 0.02
+    mask = torch.ones(2, 24, dtype=torch.long)
+    mask[1, -4:] = 0
+    labels = torch.randint(3, V, (2, 24), generator=gen)
+    labels[:, :10] = -100
+    labels[mask == 0] = -100
+    st = ParamStore(lora_param_specs(layers, D, r), DEV)
+    for n in lora_sd:
+        st.p[n].copy_(lora_sd[n])
+    lm = LlamaHIP(sd, heads, DEV)
+    lora = LoraQV(layers, D, r, 16.0, dropout, st.p, st.g, DEV)
+    lm.attach_lora(lora)
+    lora.step_seed = 3
+    loss = lm.forward_loss(emb.to(DEV), mask, labels)
+    demb = lm.backward()
+    # oracle with the same parameters under its own key convention
+    osd = dict(sd)
+    for n, t in lora_sd.items():
+        osd[n.replace(PEFT_PREFIX, "llama_model.model.layers.")] = t.clone().requires_grad_(True)
+    dmask = None
+    if dropout > 0:
+        seed = (3 * 1315423911 + 0 * 2654435761 + 12345) & 0x7FFFFFFFFFFFFFFF
+        ones = torch.ones(48, D, dtype=torch.bfloat16, device=DEV)
+        dmask = ops.dropout_bf16(ones, dropout, seed).float().cpu().view(2, 24, D)     # keep/(1-p) factors
+        assert 0.90 < float((dmask > 0).float().mean()) < 0.99
+    e = emb.clone().requires_grad_(True)
+    loss_ref, _ = R.llama_causal_lm(osd, e, mask, labels, heads, lora=dict(r=r, alpha=16.0, dropout_mask=dmask))
+    loss_ref.backward()
+    assert abs(loss.item() - loss_ref.item()) < 3e-3 * abs(loss_ref.item())
+    assert relerr(demb, e.grad) < 5e-2
+    for n in lora_sd:
+        want = osd[n.replace(PEFT_PREFIX, "llama_model.model.layers.")].grad
+        assert relerr(st.g[n], want) < 6e-2, n

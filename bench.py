@@ -236,6 +236,8 @@ def main():
 
     fl = flops_per_sample(a.arch, a.stage, cfg)
     roof = None
+    if not a.no_probe and rank != 0:
+        step(a.warmup + a.steps)          # every rank takes part in the probe step's gradient all-reduce
     if not a.no_probe and rank == 0:
         with GemmProbe() as pr:
             step(a.warmup + a.steps)

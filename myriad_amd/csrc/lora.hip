@@ -12,7 +12,7 @@
 
 #define LR_NT 256
 #define LR_NW 4
-#define LR_CH 16   // row chunks of the wgrad partial sums
+#define LR_CH 32   // row chunks of the wgrad partial sums
 
 __device__ __forceinline__ float lora_keep(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
   if (p <= 0.f) return 1.f;
@@ -84,7 +84,6 @@ __global__ __launch_bounds__(LR_NT) void lora_wgrad_partial_kernel(
     const bf16_t* __restrict__ dv, long ldq, const bf16_t* __restrict__ border, long ldb, float* __restrict__ pA,
     float* __restrict__ pBq, float* __restrict__ pBv, int M, int D, float s, float p, unsigned long long seed) {
   constexpr int r = R2 / 2;
-  __shared__ float sg[R2], st[R2];
   const int d = blockIdx.x * LR_NT + threadIdx.x;
   const int chunk = blockIdx.y;
   const int rows_per = (M + LR_CH - 1) / LR_CH;
@@ -97,12 +96,15 @@ __global__ __launch_bounds__(LR_NT) void lora_wgrad_partial_kernel(
 #pragma unroll
   for (int j = 0; j < r; ++j) { bq[j] = 0.f; bv[j] = 0.f; }
   for (int m = m0; m < m1; ++m) {
-    __syncthreads();
-    if (threadIdx.x < R2) {
-      sg[threadIdx.x] = s * dx_ext[(long)m * ldg + D + threadIdx.x];
-      st[threadIdx.x] = bf2f(border[(long)m * ldb + threadIdx.x]);
+    // the 2*R2 per-row scalars are wave-uniform addresses: the compiler turns them into scalar (s_load) reads
+    float sg[R2], st[R2];
+    const float* grow = dx_ext + (long)m * ldg + D;
+    const bf16_t* brow = border + (long)m * ldb;
+#pragma unroll
+    for (int j = 0; j < R2; ++j) {
+      sg[j] = s * grow[j];
+      st[j] = bf2f(brow[j]);
     }
-    __syncthreads();
     if (d < D) {
       const float xd = bf2f(x[(long)m * ldx + d]) * lora_keep(seed, (unsigned long long)((long)m * D + d), p, ik);
       const float gq = bf2f(dq[(long)m * ldq + d]), gv = bf2f(dv[(long)m * ldq + d]);

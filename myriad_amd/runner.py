@@ -113,8 +113,12 @@ def init_distributed(backend: Optional[str] = None):
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = int(os.environ.get("LOCAL_RANK", rank))
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
-    if backend == "nccl":
+        # MYRIAD_DIST_BACKEND=gloo + MYRIAD_SINGLE_DEVICE=1: exercise the N>1 control flow with every rank on cuda:0
+        # (one-GPU test boxes; NCCL/RCCL refuses two ranks per device).  Production: nccl (= RCCL on ROCm).
+        backend = os.environ.get("MYRIAD_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+    if os.environ.get("MYRIAD_SINGLE_DEVICE") == "1":
+        local = 0
+    if torch.cuda.is_available():
         torch.cuda.set_device(local)
     dist.init_process_group(backend=backend, init_method="env://", world_size=world, rank=rank)
     dist.barrier()

@@ -212,18 +212,21 @@ def main():
     sched = LinearWarmupCosineLRScheduler(None, max_epoch=10, iters_per_epoch=1600, min_lr=0.0, init_lr=1e-4,
                                           warmup_steps=0, warmup_start_lr=1e-6)   # shipped recipe
     samples = make_samples(a.batch, cfg["vocab"], 42 + rank, dev)
-    allreduce = dp.allreduce if world > 1 else None
+    overlap = os.environ.get("MYRIAD_NO_OVERLAP") != "1"
 
     def step(i, smp=samples):
-        return model.train_step(smp, sched.step(0, i), 0.05, allreduce=allreduce, world=world)
+        # N>1: the gradient all-reduce (RCCL, side stream) + AdamW of step i are applied under step i+1's ViT forward
+        return model.train_step(smp, sched.step(0, i), 0.05, dp=dp if world > 1 else None, world=world, overlap=overlap)
 
     for i in range(a.warmup):
         step(i)
+    model.finish_update()
     dp.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(a.steps):
         loss = step(a.warmup + i)
+    model.finish_update()                 # the last step's optimiser update is inside the timed region
     dp.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
@@ -238,9 +241,11 @@ def main():
     roof = None
     if not a.no_probe and rank != 0:
         step(a.warmup + a.steps)          # every rank takes part in the probe step's gradient all-reduce
+        model.finish_update()
     if not a.no_probe and rank == 0:
         with GemmProbe() as pr:
             step(a.warmup + a.steps)
+            model.finish_update()
             gs = pr.summary()
         if os.environ.get("BENCH_SHAPES"):
             with open(os.environ["BENCH_SHAPES"], "w") as f:

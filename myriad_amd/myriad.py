@@ -172,6 +172,7 @@ class MyriadHIP(nn.Module):
                                float(cfg.get("lora_alpha", 16)), float(cfg.get("lora_dropout", 0.05)),
                                self.store.p, self.store.g, self._dev)
             self.llama.attach_lora(self.lora)
+        self._pending_update = None
         self._anchor = torch.zeros((), device=self._dev, requires_grad=True)
         self._ctx = None
 
@@ -265,10 +266,10 @@ class MyriadHIP(nn.Module):
             tgt, tmask = enc.input_ids, enc.attention_mask
         return before, after, tgt, tmask
 
-    def encode_img(self, image, maps, stage, save=True):
+    def encode_img(self, image, maps, stage, save=True, vit_out=None):
         """`Myriad.encode_img` (myriad.py:241-272).  Returns img tokens [B, n_img, Dl] f32."""
         B = image.shape[0]
-        x = self.visual_encoder.forward(image)                      # [B,257,Dv] f32, frozen
+        x = vit_out if vit_out is not None else self.visual_encoder.forward(image)   # [B,257,Dv] f32, frozen
         N = x.shape[1]
         x2 = x.view(B * N, self.Dv)
         y = self.adaptor.forward(x2, save) if self.arch == "myriad" else x2
@@ -328,16 +329,19 @@ class MyriadHIP(nn.Module):
             labels = torch.cat([torch.full((B, 1 + nb + n_img + na), -100, dtype=torch.long), targets], 1)
         return emb, attn, labels, img_slices
 
-    def _forward_impl(self, samples, need_grad: bool):
+    def _image_of(self, samples):
+        image = samples["image"]
+        if "aug_image" in samples and self.training:
+            image = torch.cat([image, samples["aug_image"]])          # myriad.py:315-316
+        return image.to(self._dev, F32)
+
+    def _forward_impl(self, samples, need_grad: bool, vit_out=None):
         if self.use_lora:
             self.lora.step_seed = (self.lora.step_seed + 1) if need_grad else self.lora.step_seed
         stage = self.fixed_stage if self.fixed_stage is not None else random.choice([0, 1, 2])   # myriad.py:378
         if self.arch != "myriad":
             stage = 0
-        image = samples["image"]
-        if "aug_image" in samples and self.training:
-            image = torch.cat([image, samples["aug_image"]])          # myriad.py:315-316
-        image = image.to(self._dev, F32)
+        image = self._image_of(samples)
         maps = None
         if self.arch == "myriad":
             task = self.fixed_taskstage if self.fixed_taskstage is not None else random.choice([0, 1])  # :381
@@ -347,7 +351,7 @@ class MyriadHIP(nn.Module):
                                "(SURVEY 2.1 row 10)")
             maps = samples[key].to(self._dev, F32)
         before, after, tgt, tmask = self._tokenize(samples, image.shape[0], stage, True)
-        parts = self.encode_img(image, maps, stage, need_grad)
+        parts = self.encode_img(image, maps, stage, need_grad, vit_out=vit_out)
         emb, attn, labels, img_slices = self._assemble(parts, before, after, tgt, tmask)
         loss = self.llama.forward_loss(emb, attn, labels, save_for_backward=need_grad)
         if need_grad:
@@ -411,16 +415,41 @@ class MyriadHIP(nn.Module):
             if prm.grad is None or prm.grad.data_ptr() != self.store.g[name].data_ptr():
                 prm.grad = self.store.g[name]
 
-    def train_step(self, samples, lr: float, weight_decay: float = 0.05, allreduce=None, world: int = 1):
+    def train_step(self, samples, lr: float, weight_decay: float = 0.05, allreduce=None, world: int = 1, dp=None,
+                   overlap: bool = True):
         """forward + backward (+ gradient all-reduce) + fused AdamW: one optimisation step of
-        `BaseTask._train_inner_loop` (base_task.py:233-271) without the autograd bridge."""
+        `BaseTask._train_inner_loop` (base_task.py:233-271) without the autograd bridge.
+        With a `DataParallel` (`dp`) and overlap=True the all-reduce + AdamW of step t are hidden behind the frozen
+        ViT forward of step t+1 (95 % of the gradient bytes only exist after the whole LLaMA backward, so
+        overlapping with backward hides nothing); call `finish_update()` after the last step."""
         with torch.no_grad():
-            loss = self._forward_impl(samples, True)
+            vit_out = None
+            if self._pending_update is not None:
+                # The previous step's gradient all-reduce is still in flight on the side stream: run this step's
+                # frozen ViT forward (independent of the update) under it, then apply the delayed AdamW.
+                vit_out = self.visual_encoder.forward(self._image_of(samples))
+                self.finish_update()
+            loss = self._forward_impl(samples, True, vit_out=vit_out)
             self.backward()
-            if allreduce is not None:
-                allreduce(self.store.flat_g)
-            self.store.adamw_step(lr, weight_decay, grad_scale=1.0 / world)
+            if dp is not None and dp.world > 1 and overlap:
+                dp.start(self.store.flat_g)                       # RCCL all-reduce(sum) on the side HIP stream
+                self._pending_update = (dp, lr, weight_decay)
+            else:
+                if dp is not None and dp.world > 1:
+                    dp.allreduce(self.store.flat_g)
+                elif allreduce is not None:
+                    allreduce(self.store.flat_g)
+                    world = max(world, 1)
+                self.store.adamw_step(lr, weight_decay, grad_scale=1.0 / (dp.world if dp is not None else world))
         return loss
+
+    def finish_update(self):
+        """Apply a delayed optimiser update (overlap mode): wait for the gradient all-reduce, then fused AdamW."""
+        if self._pending_update is not None:
+            dp, lr, wd = self._pending_update
+            dp.wait()
+            self.store.adamw_step(lr, wd, grad_scale=1.0 / dp.world)
+            self._pending_update = None
 
     @torch.no_grad()
     def generate(self, samples, **generate_kwargs):

@@ -135,9 +135,9 @@ def train_loop(model, data_iter: Callable[[], dict], n_steps: int, scheduler: Li
     for i in range(n_steps):
         lr = scheduler.step(cur_epoch=epoch, cur_step=i)
         samples = data_iter()
-        loss = model.train_step(samples, lr, weight_decay, allreduce=(dp.allreduce if dp and world > 1 else None),
-                                world=world)
+        loss = model.train_step(samples, lr, weight_decay, dp=(dp if dp and world > 1 else None), world=world)
         losses.append(loss)
         if log is not None:
             log(i, float(loss), lr)      # device->host sync per step like metric_logger.update(loss.item())
+    model.finish_update()                # flush the delayed (overlapped) optimiser update of the last step
     return losses

@@ -246,6 +246,64 @@ def test_networks_vs_golden():
                 assert stem_grad_close(st.g[pre + f"meta_net.{idx}.bias"][:64], g[f"{nm}_db{idx}"]), (nm, idx)
 
 
+class _TwoIdenticalRanks:
+    """Stand-in for myriad_amd.runner.DataParallel with world 2 whose peer holds the same gradient: the async
+    all-reduce(sum) returns 2*g at wait() time."""
+    world = 2
+
+    def start(self, flat):
+        self.flat = flat
+
+    def wait(self):
+        self.flat.mul_(2.0)
+
+    def allreduce(self, flat):
+        flat.mul_(2.0)
+
+
+def test_overlapped_update_equals_synchronous_update(composite):
+    """Delaying all-reduce + AdamW of step t behind the ViT forward of step t+1 must not change the trajectory."""
+    g, sd, batch = composite
+    smp = _samples(batch)
+    runs = []
+    for overlap in (False, True):
+        model = MyriadHIP(sd, dict(fixed_stage=1, fixed_taskstage=0), device=DEV)
+        dp = _TwoIdenticalRanks()
+        losses = [float(model.train_step(smp, lr=1e-3, dp=dp, overlap=overlap)) for _ in range(3)]
+        model.finish_update()
+        runs.append((losses, model.store.flat_p.clone()))
+    assert runs[0][0] == pytest.approx(runs[1][0], rel=1e-6)
+    assert relerr(runs[1][1], runs[0][1]) < 1e-6
+    assert runs[0][0][2] < runs[0][0][0]
+
+
+def test_myriad_generate_token_ids_vs_oracle(composite):
+    """`Myriad.generate` (stage-1 layout, no BOS, KV-cache greedy decode, row-0 stop rule) against the oracle:
+    generated ids are equal at every step whose oracle top-1/top-2 logit margin is >= 0.1."""
+    g, sd, batch = composite
+    image, maps, before, after, tgt, tmask = batch
+    model = MyriadHIP(sd, dict(need_backward=False), device=DEV)
+    model.eval()
+    smp = dict(image=image, anomaly_maps=maps, before_ids=before, after_ids=after)
+    out = model.generate(smp, max_new_tokens=10, stop_ids=((5,),))
+    ids = out["token_ids"]
+    assert out["ve_anomaly_maps"].shape == maps.shape
+    with torch.no_grad():
+        img = R.encode_img(sd, image, maps, 1, "myriad")
+        ew = sd["llama_model.model.embed_tokens.weight"]
+        wrapped = torch.cat([ew[before], img, ew[after]], 1)
+        ids_ref, margins = R.greedy_generate(sd, wrapped, 32, max_new_tokens=10, stop_ids=((5,),), return_margins=True)
+    n = min(ids.shape[1], ids_ref.shape[1])
+    assert n >= 1
+    checked = 0
+    for t in range(n):
+        if float(margins[:, t].min()) < 0.1:
+            break
+        assert torch.equal(ids[:, t], ids_ref[:, t]), (t, ids, ids_ref, margins)
+        checked += 1
+    assert checked >= 1, margins
+
+
 def test_train_step_moves_parameters_like_adamw(composite):
     g, sd, batch = composite
     model = MyriadHIP(sd, dict(fixed_stage=1, fixed_taskstage=0), device=DEV)

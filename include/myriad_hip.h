@@ -136,6 +136,11 @@ int mh_gather_rows_f32_to_bf16(const float* src, long lds, const int* rows, void
 int mh_gather_rows_f32(const float* src, long lds, const int* rows, float* dst, long n, int D, mh_stream_t s);
 int mh_copy3d_bf16(const void* src, long src_bstride, long lds, void* dst, long dst_bstride, long ldd, int nb,
                    long rows, int cols, mh_stream_t s);
+/* KV-cache append at a device-resident position + device counter bump: lets one decode step be captured in a
+ * hipGraph and replayed per token (modeling_llama.py:190-195 concatenates; the cache is written in place). */
+int mh_kv_append_bf16(const void* src, long ld_src, void* cache, long cache_bstride, long ld_cache, const int* pos_dev,
+                      int B, int cols, mh_stream_t s);
+int mh_add_i32(int* x, int n, int delta, mh_stream_t s);
 /* K14 patch embedding operand (eva_vit.py:196-204): NCHW f32 image -> [B*np, Kpad] bf16 in (c,iy,ix) order */
 int mh_patchify_nchw(const float* img, void* out, int B, int C, int H, int W, int P, int Kpad, mh_stream_t s);
 int mh_scatter_rows_f32(const float* src, const int* rows, float* dst, long ldd, long n, int D, int accumulate,

@@ -137,8 +137,9 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
 
   for (int k0 = 0; k0 < kv_end; k0 += TK) {
     __syncthreads();
-    stage_rowmajor<DP>(Ks, kb, p.ldk, k0, p.Sk, p.D);
-    stage_transposed<DP>(Vt, vb, p.ldv, k0, p.Sk, p.D);
+    // rows >= kv_valid are zero-filled: an unwritten KV-cache row may hold NaN/Inf and 0 * NaN = NaN in the MFMA
+    stage_rowmajor<DP>(Ks, kb, p.ldk, k0, kv_valid, p.D);
+    stage_transposed<DP>(Vt, vb, p.ldv, k0, kv_valid, p.D);
     __syncthreads();
     float4_t s[4];
 #pragma unroll
@@ -259,9 +260,9 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 
   for (int k0 = 0; k0 < kv_end; k0 += TK) {
     __syncthreads();
-    stage_rowmajor<DP>(Ks, kb, p.ldk, k0, p.Sk, p.D);
-    stage_rowmajor<DP>(Vs, vb, p.ldv, k0, p.Sk, p.D);
-    stage_transposed<DP>(Kt, kb, p.ldk, k0, p.Sk, p.D);
+    stage_rowmajor<DP>(Ks, kb, p.ldk, k0, kv_valid, p.D);
+    stage_rowmajor<DP>(Vs, vb, p.ldv, k0, kv_valid, p.D);
+    stage_transposed<DP>(Kt, kb, p.ldk, k0, kv_valid, p.D);
     __syncthreads();
     float4_t s[4], dp[4];
 #pragma unroll
@@ -283,7 +284,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
         float val = s[j][r] * p.scale;
         if (p.bias && ok) val += p.bias[((long)h * p.Sq + qi) * p.Sk + key];
         const float pr = ok ? __expf(val - lse) : 0.f;
-        s[j][r] = pr * (dp[j][r] - dlt) * p.scale;  // dS
+        s[j][r] = ok ? pr * (dp[j][r] - dlt) * p.scale : 0.f;  // dS (select, not multiply: masked dp may be non-finite)
       }
     const short8_t d0 = pack8(s[0], s[1]), d1 = pack8(s[2], s[3]);
 #pragma unroll
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
         if (p.bias && ok) val += p.bias[((long)h * p.Sq + qq) * p.Sk + ki];
         const float e = ok ? __expf(val - l4[r]) : 0.f;
         pr[j][r] = e;
-        s[j][r] = e * (dp[j][r] - d4[r]) * p.scale;
+        s[j][r] = ok ? e * (dp[j][r] - d4[r]) * p.scale : 0.f;
       }
     }
     const short8_t p0 = pack8(pr[0], pr[1]), p1 = pack8(pr[2], pr[3]);
@@ -420,16 +421,20 @@ static int check_common(const AttnParams& p) {
   return MH_OK;
 }
 
-template <typename K>
-static void allow_lds(K kern, size_t bytes) {
-  // > 64 KiB of dynamic LDS needs an explicit opt-in (gfx950 has 160 KiB per CU)
-  if (bytes > 48 * 1024) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+template <void (*KERN)(AttnParams)>
+static void allow_lds(size_t bytes) {
+  // > 64 KiB of dynamic LDS needs an explicit opt-in (gfx950 has 160 KiB per CU).  Once per kernel instantiation
+  // (the static lives in this template instance), so nothing but the launch happens during hipGraph capture.
+  static bool done = false;
+  if (!done && bytes > 48 * 1024)
+    (void)hipFuncSetAttribute((const void*)KERN, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+  done = true;
 }
 
 template <int DP>
 static int launch_fwd(const AttnParams& p, hipStream_t s) {
   const size_t sh = Lds<DP>::RM_BYTES + Lds<DP>::TR_BYTES;
-  allow_lds(attn_fwd_kernel<DP>, sh);
+  allow_lds<attn_fwd_kernel<DP>>(sh);
   hipLaunchKernelGGL(attn_fwd_kernel<DP>, dim3((p.Sq + TQ - 1) / TQ, p.B * p.H), dim3(256), sh, s, p);
   MH_CHECK_LAUNCH();
   return MH_OK;
@@ -437,11 +442,11 @@ static int launch_fwd(const AttnParams& p, hipStream_t s) {
 template <int DP>
 static int launch_bwd(const AttnParams& p, hipStream_t s) {
   const size_t sh_dq = 2 * Lds<DP>::RM_BYTES + Lds<DP>::TR_BYTES;
-  allow_lds(attn_bwd_dq_kernel<DP>, sh_dq);
+  allow_lds<attn_bwd_dq_kernel<DP>>(sh_dq);
   hipLaunchKernelGGL(attn_bwd_dq_kernel<DP>, dim3((p.Sq + TQ - 1) / TQ, p.B * p.H), dim3(256), sh_dq, s, p);
   MH_CHECK_LAUNCH();
   const size_t sh_kv = 2 * Lds<DP>::RM_BYTES + 2 * Lds<DP>::TR_BYTES + 512;
-  allow_lds(attn_bwd_dkv_kernel<DP>, sh_kv);
+  allow_lds<attn_bwd_dkv_kernel<DP>>(sh_kv);
   hipLaunchKernelGGL(attn_bwd_dkv_kernel<DP>, dim3((p.Sk + TK - 1) / TK, p.B * p.H), dim3(256), sh_kv, s, p);
   MH_CHECK_LAUNCH();
   return MH_OK;

@@ -515,3 +515,37 @@ extern "C" int mh_dropout_add_f32(const float* dy, long lddy, float* acc, long l
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
+
+// ---- KV-cache append at a DEVICE-resident position (so the decode step can be replayed from a hipGraph) ----------
+// cache[b, pos[0], :] = src[b, :]   (reference modeling_llama.py:190-195 concatenates; we write in place)
+__global__ void kv_append_kernel(const bf16_t* __restrict__ src, long ld_src, bf16_t* __restrict__ cache, long cache_bs,
+                                 long ld_cache, const int* __restrict__ pos, int B, int cols8) {
+  const long total = (long)B * cols8;
+  const long p = pos[0];
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long b = it / cols8;
+    const int c = (int)(it - b * cols8) * 8;
+    *reinterpret_cast<short8_t*>(cache + b * cache_bs + p * ld_cache + c) =
+        *reinterpret_cast<const short8_t*>(src + b * ld_src + c);
+  }
+}
+extern "C" int mh_kv_append_bf16(const void* src, long ld_src, void* cache, long cache_bstride, long ld_cache,
+                                 const int* pos_dev, int B, int cols, hipStream_t stream) {
+  if (B <= 0 || cols <= 0) return MH_OK;
+  if (cols % 8 || ld_src % 8 || ld_cache % 8 || cache_bstride % 8) return MH_ERR_ARG;
+  hipLaunchKernelGGL(kv_append_kernel, dim3(ew_grid((long)B * (cols / 8))), dim3(EW_NT), 0, stream, (const bf16_t*)src,
+                     ld_src, (bf16_t*)cache, cache_bstride, ld_cache, pos_dev, B, cols / 8);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+__global__ void add_i32_kernel(int* x, int n, int delta) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] += delta;
+}
+extern "C" int mh_add_i32(int* x, int n, int delta, hipStream_t stream) {
+  if (n <= 0) return MH_OK;
+  hipLaunchKernelGGL(add_i32_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, x, n, delta);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}

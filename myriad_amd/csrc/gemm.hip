@@ -361,6 +361,9 @@ extern "C" int mh_set_workspace(void* ptr, long bytes) {
   return MH_OK;
 }
 
+int mh_launch_gemv(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                   const float* bias, const float* residual, int ldr, int out_f32, float alpha, hipStream_t stream);
+
 static int auto_splits(int M, int N, int K) {
   const long tiles = (long)((M + BM - 1) / BM) * ((N + 127) / 128);
   const int kt = K / 64;
@@ -380,6 +383,10 @@ extern "C" int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   if ((ldc % 4) != 0 || (residual && (ldr % 4) != 0)) return MH_ERR_ARG;
   GemmArgs g = {A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, flags, alpha, 1, K / 64, 0L};
   const int variant = (flags >> MH_GEMM_VARIANT_SHIFT) & 15;
+  // decode / tiny-M: weight-streaming kernel (gemv.hip) instead of the 128-row training tile
+  if (variant == 0 && M <= 16 && !(flags & (MH_GEMM_REGSTAGE | MH_GEMM_GELU)))
+    return mh_launch_gemv(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, (flags & MH_GEMM_OUT_F32) ? 1 : 0, alpha,
+                          stream);
   if (variant == 0 && !(flags & MH_GEMM_REGSTAGE) && g_ws) {
     const int s = auto_splits(M, N, K);
     // the reduce reads `residual` and writes C element-wise, so C may alias residual (in-place accumulate)

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(LNT) void argmax_kernel(const float* __restrict__ l
   const long row = blockIdx.x;
   const float* x = logits + row * ldl;
   float best = -__builtin_inff(), second = -__builtin_inff();
-  int bi = 0x7fffffff;
+  int bi = threadIdx.x < V ? threadIdx.x : 0;   // stays in range even if every logit is NaN
   for (int j = threadIdx.x; j < V; j += LNT) {
     const float v = (j == ban_id) ? -__builtin_inff() : x[j];
     if (v > best) { second = best; best = v; bi = j; }

@@ -189,64 +189,111 @@ class LlamaHIP:
         return dh.view(B, S, D)
 
     # ------------------------------------------------------------------ generation
+    # ------------------------------------------------------------------ generation
+    def _decode_block(self, h, B, S, caches, scale, pos, past=None, pos_dev=None, kvlen_dev=None):
+        """All decoder layers for a prefill chunk (host-known `past`) or for one decode token whose position lives
+        in device memory (`pos_dev`/`kvlen_dev`), which makes the launch sequence replayable from a hipGraph."""
+        H, hd, W, D = self.H, self.hd, self.D, self.D
+        M = B * S
+        for li, (L, cache) in enumerate(zip(self.layers, caches)):
+            if self.lora is None:
+                xn = ops.rmsnorm_fwd(h, L["ln1"], self.eps)
+                qkv = ops.gemm(xn, L["wqkv"])
+            else:
+                x_ext = self.lora.x_ext(li, M)
+                ops.rmsnorm_fwd(h, L["ln1"], self.eps, out=x_ext[:, :D])
+                self.lora.forward_border(li, x_ext, training=False)
+                qkv = ops.gemm(x_ext, L["wqkv_ext"])
+            ops.rope_(qkv, 0, 2 * H, hd, pos, self.cos, self.sin, 1.0)
+            q3 = qkv.view(B, S, 3 * W)
+            if pos_dev is None:
+                ops.copy3d_bf16(q3[:, :, W:], cache[:, past:past + S])       # append k|v (modeling_llama.py:190-195)
+                kc = cache[:, :past + S]
+                o, _ = ops.attn_fwd(q3[:, :, :W], kc[:, :, :W], kc[:, :, W:], H, hd, scale, causal=True, need_lse=False)
+            else:
+                ops.kv_append(qkv[:, W:], cache, pos_dev)
+                o, _ = ops.attn_fwd(q3[:, :, :W], cache[:, :, :W], cache[:, :, W:], H, hd, scale, causal=False,
+                                    kv_len=kvlen_dev, need_lse=False)
+            h2 = ops.gemm(o.view(M, W), L["wo"], residual=h, out_dtype=F32)
+            xn2 = ops.rmsnorm_fwd(h2, L["ln2"], self.eps)
+            act = ops.silu_mul_fwd(ops.gemm(xn2, L["wgu"]))
+            h = ops.gemm(act, L["wd"], residual=h2, out_dtype=F32)
+        return h
+
     @torch.no_grad()
     def greedy_generate(self, inputs_embeds: torch.Tensor, max_new_tokens: int = 90,
                         stop_ids=((835,), (2277, 29937)), eos_id: int = 2, min_length: int = 1,
-                        return_margins: bool = False):
+                        return_margins: bool = False, use_graph: bool = True):
         """Greedy decode from [B,S0,D] f32 embeddings with a KV cache (prefill + 1-token steps).  Same contract
         as the oracle's greedy_generate: stop when ROW 0 ends with a stop sequence (conversation.py:102-107),
-        EOS banned while fewer than `min_length` tokens were generated, finished rows padded with EOS."""
+        EOS banned while fewer than `min_length` tokens were generated, finished rows padded with EOS.
+        The single-token step is launch-bound (~420 kernels per token), so after one eager step it is captured
+        into a hipGraph and replayed: position / valid-length counters live in device memory."""
         B, S0, D = inputs_embeds.shape
-        H, hd, W = self.H, self.hd, self.D
         T = S0 + max_new_tokens
-        scale = 1.0 / math.sqrt(hd)
-        caches = [torch.empty((B, T, 2 * W), dtype=BF16, device=self.dev) for _ in self.layers]
+        scale = 1.0 / math.sqrt(self.hd)
+        caches = [torch.zeros((B, T, 2 * self.D), dtype=BF16, device=self.dev) for _ in self.layers]
         out_ids, margins = [], []
         unfinished = torch.ones(B, dtype=torch.long)
-        x = inputs_embeds.reshape(B * S0, D).contiguous()
-        S, past = S0, 0
-        for step in range(max_new_tokens):
-            M = B * S
-            pos = (torch.arange(S, dtype=torch.int32) + past).repeat(B).to(self.dev)
-            h = x
-            if self.lora is not None and step == 0:
-                self.lora.refresh(self.layers)
-            for li, (L, cache) in enumerate(zip(self.layers, caches)):
-                if self.lora is None:
-                    xn = ops.rmsnorm_fwd(h, L["ln1"], self.eps)
-                    qkv = ops.gemm(xn, L["wqkv"])
-                else:
-                    x_ext = self.lora.x_ext(li, M)
-                    ops.rmsnorm_fwd(h, L["ln1"], self.eps, out=x_ext[:, :D])
-                    self.lora.forward_border(li, x_ext, training=False)
-                    qkv = ops.gemm(x_ext, L["wqkv_ext"])
-                ops.rope_(qkv, 0, 2 * H, hd, pos, self.cos, self.sin, 1.0)
-                q3 = qkv.view(B, S, 3 * W)
-                ops.copy3d_bf16(q3[:, :, W:], cache[:, past:past + S])       # append k|v
-                kc = cache[:, :past + S]
-                o, _ = ops.attn_fwd(q3[:, :, :W], kc[:, :, :W], kc[:, :, W:], H, hd, scale, causal=True, need_lse=False)
-                h2 = ops.gemm(o.view(M, W), L["wo"], residual=h, out_dtype=F32)
-                xn2 = ops.rmsnorm_fwd(h2, L["ln2"], self.eps)
-                act = ops.silu_mul_fwd(ops.gemm(xn2, L["wgu"]))
-                h = ops.gemm(act, L["wd"], residual=h2, out_dtype=F32)
-            last = h.view(B, S, D)[:, -1].contiguous()
-            logits = ops.gemm(ops.rmsnorm_fwd(last, self.norm, self.eps), self.lm_head, out_dtype=F32)
+        if self.lora is not None:
+            self.lora.refresh(self.layers)
+
+        def finish(logits, step):
             ban = eos_id if step < min_length else -1
-            nxt_d, mar = ops.argmax_rows(logits, ban_id=ban, want_margin=True)
+            return ops.argmax_rows(logits, ban_id=ban, want_margin=True)
+
+        def record(nxt_d, mar_d):
+            nonlocal unfinished
             nxt = nxt_d.cpu()
-            margins.append(mar.cpu())
-            nxt = nxt * unfinished + eos_id * (1 - unfinished)
+            margins.append(mar_d.cpu())
+            nxt = nxt * unfinished + eos_id * (1 - unfinished)       # HF pads finished rows with pad(=eos)
             unfinished = unfinished * (nxt != eos_id).long()
             out_ids.append(nxt)
             row0 = [int(t[0]) for t in out_ids]
-            if any(len(row0) >= len(s) and row0[-len(s):] == list(s) for s in stop_ids):
-                break
-            if int(unfinished.max()) == 0:
-                break
-            past += S
-            S = 1
-            x = torch.empty((B, D), dtype=F32, device=self.dev)
-            ops.embed_gather(self.embed, nxt.to(self.dev), x)
+            if any(len(row0) >= len(st) and row0[-len(st):] == list(st) for st in stop_ids):
+                return True
+            return int(unfinished.max()) == 0
+
+        # ---- prefill
+        pos = torch.arange(S0, dtype=torch.int32).repeat(B).to(self.dev)
+        h = self._decode_block(inputs_embeds.reshape(B * S0, D).contiguous(), B, S0, caches, scale, pos, past=0)
+        last = h.view(B, S0, D)[:, -1].contiguous()
+        logits = ops.gemm(ops.rmsnorm_fwd(last, self.norm, self.eps), self.lm_head, out_dtype=F32)
+        nxt_d, mar_d = finish(logits, 0)
+        done = record(nxt_d, mar_d)
+
+        # ---- single-token steps; device-resident counters
+        pos_dev = torch.full((B,), S0, dtype=torch.int32, device=self.dev)        # position of the incoming token
+        kvlen_dev = torch.full((B,), S0 + 1, dtype=torch.int32, device=self.dev)  # valid keys after the append
+        ids_dev = torch.empty((B,), dtype=torch.long, device=self.dev)
+        x_in = torch.empty((B, D), dtype=F32, device=self.dev)
+        nxt_out = torch.empty((B,), dtype=torch.long, device=self.dev)
+        mar_out = torch.empty((B,), dtype=F32, device=self.dev)
+
+        def token_step(ban):
+            ops.embed_gather(self.embed, ids_dev, x_in)
+            hh = self._decode_block(x_in, B, 1, caches, scale, pos_dev, pos_dev=pos_dev, kvlen_dev=kvlen_dev)
+            lg = ops.gemm(ops.rmsnorm_fwd(hh, self.norm, self.eps), self.lm_head, out_dtype=F32)
+            ops.argmax_rows(lg, ban_id=ban, want_margin=True, out=nxt_out, margin_out=mar_out)
+            ops.add_i32_(pos_dev, 1)
+            ops.add_i32_(kvlen_dev, 1)
+
+        graph = None
+        step = 1
+        while not done and step < max_new_tokens:
+            ids_dev.copy_(out_ids[-1].to(self.dev))
+            ban = eos_id if step < min_length else -1
+            if graph is not None:
+                graph.replay()
+            else:
+                token_step(ban)
+                if use_graph and ban == -1 and max_new_tokens - step > 4:
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        token_step(-1)
+            done = record(nxt_out, mar_out)
+            step += 1
         ids = torch.stack(out_ids, 1)
         if return_margins:
             return ids, torch.stack(margins, 1)

@@ -362,10 +362,25 @@ def sum_f32(x: torch.Tensor, scale: float = 1.0):
     return out
 
 
-def argmax_rows(logits: torch.Tensor, ban_id: int = -1, want_margin: bool = False):
+def kv_append(src2d: torch.Tensor, cache: torch.Tensor, pos_dev: torch.Tensor):
+    """cache[b, pos_dev[0], :] = src2d[b, :] with the position read on the device (graph-replayable)."""
+    B, cols = src2d.shape
+    _lib.check(_L().mh_kv_append_bf16(_p(src2d), src2d.stride(0), _p(cache), cache.stride(0), cache.stride(1),
+                                      _p(pos_dev), B, cols, _s()), "mh_kv_append_bf16")
+
+
+def add_i32_(x: torch.Tensor, delta: int):
+    _lib.check(_L().mh_add_i32(_p(x), x.numel(), int(delta), _s()), "mh_add_i32")
+    return x
+
+
+def argmax_rows(logits: torch.Tensor, ban_id: int = -1, want_margin: bool = False, out=None, margin_out=None):
     R, V = logits.shape
-    out = torch.empty((R,), dtype=torch.long, device=logits.device)
-    margin = torch.empty((R,), dtype=F32, device=logits.device) if want_margin else None
+    if out is None:
+        out = torch.empty((R,), dtype=torch.long, device=logits.device)
+    margin = margin_out
+    if margin is None and want_margin:
+        margin = torch.empty((R,), dtype=F32, device=logits.device)
     _lib.check(_L().mh_argmax_rows(_p(logits), logits.stride(0), _p(out), _p(margin), R, V, ban_id, _s()),
                "mh_argmax_rows")
     return (out, margin) if want_margin else out

@@ -104,6 +104,20 @@ def test_gemm_auto_splitk_epilogue(M, N, K):
     assert relerr(acc, ref + res) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 12288, 4160), (16, 1000, 11008), (3, 32000, 4096)])
+def test_skinny_m_weight_streaming_gemm(M, N, K):
+    """M <= 16 routes to the decode weight-streaming kernel (gemv.hip)."""
+    a = bf(rnd(M, K, seed=15)).to(DEV)
+    b = bf(rnd(N, K, seed=16) * 0.05 + torch.arange(N)[:, None] * 1e-4).to(DEV)
+    bias = rnd(N, seed=17).to(DEV)
+    res = rnd(M, N, seed=18).to(DEV)
+    ref = a.float() @ b.float().T
+    assert relerr(ops.gemm(a, b, out_dtype=torch.float32), ref) < 1e-4
+    assert relerr(ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32, alpha=0.5), 0.5 * ref + bias + res) < 1e-4
+    assert relerr(ops.gemm(a, b).float(), ref) < 6e-3
+    assert relerr(ops.gemm(a, b, out_dtype=torch.float32), ops.gemm(a, b, out_dtype=torch.float32, variant=1)) < 1e-4
+
+
 def test_gemm_rejects_bad_k():
     a = bf(rnd(8, 40)).to(DEV)
     b = bf(rnd(8, 40)).to(DEV)

@@ -1,0 +1,31 @@
+#!/usr/bin/env python3
+"""Greedy-decode throughput of the full-size model: prefill + N single-token steps with KV cache.
+python tools/decode_bench.py [--batch 1] [--new 32]"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from myriad_amd.myriad import MyriadHIP
+from myriad_amd.synthetic import SyntheticWeights, full_config
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--batch", type=int, default=1)
+ap.add_argument("--new", type=int, default=32)
+ap.add_argument("--llm-layers", type=int, default=32)
+a = ap.parse_args()
+dev = "cuda:0"
+cfg = full_config(llm_layers=a.llm_layers)
+model = MyriadHIP(SyntheticWeights(cfg, dev, seed=0), dict(need_backward=False), device=dev)
+model.eval()
+g = torch.Generator().manual_seed(1)
+B = a.batch
+smp = dict(image=torch.randn(B, 3, 224, 224, generator=g), anomaly_maps=torch.rand(B, 1, 224, 224, generator=g),
+           before_ids=torch.randint(3, 32000, (1, 4), generator=g).expand(B, -1).contiguous(),
+           after_ids=torch.randint(3, 32000, (1, 28), generator=g).expand(B, -1).contiguous())
+for n in (2, a.new):      # warm-up then timed
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = model.generate(smp, max_new_tokens=n, stop_ids=((-1,),), min_length=0, eos_token_id=-5)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+print(f"batch {B}: {out['token_ids'].shape[1]} tokens in {dt*1e3:.1f} ms (incl. ViT+Q-Former+prefill) -> "
+      f"{B * out['token_ids'].shape[1] / dt:.1f} tok/s, {dt * 1e3 / out['token_ids'].shape[1]:.2f} ms/token-step")

@@ -271,6 +271,14 @@ static int launch_gemm(const GemmArgs& g, hipStream_t stream) {
   return MH_OK;
 }
 
+int mh_launch_gemm_pp(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                      const float* bias, const float* residual, int ldr, int flags, float alpha, int splits, int tps,
+                      long split_stride, hipStream_t stream);
+
+int mh_launch_gemm_256(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                       const float* bias, const float* residual, int ldr, int flags, float alpha, int splits, int tps,
+                       long split_stride, hipStream_t stream);
+
 static int dispatch(const GemmArgs& g, hipStream_t stream) {
   int variant = (g.flags >> MH_GEMM_VARIANT_SHIFT) & 15;
   if (g.flags & MH_GEMM_REGSTAGE) return launch_gemm<1, 2, 128, 2>(g, stream);
@@ -286,6 +294,12 @@ static int dispatch(const GemmArgs& g, hipStream_t stream) {
     case 8: return launch_gemm<0, 4, 128, 2, 32>(g, stream);   // BK=32: 64 KiB, 2 blocks/CU, 3 tiles in flight
     case 9: return launch_gemm<0, 2, 128, 2, 64, 8>(g, stream);   // 8 waves/block (wave tile 32x64), 2 blocks/CU
     case 10: return launch_gemm<0, 4, 128, 1, 64, 8>(g, stream);  // 8 waves/block, 4-deep ring, 1 block/CU
+    case 11:                                                      // 256x128 ping-pong (gemm_pp.hip), 1 block/CU
+      return mh_launch_gemm_pp(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, g.bias, g.residual, g.ldr, g.flags,
+                               g.alpha, g.splits, g.tps, g.split_stride, stream);
+    case 12:                                                      // 256x256x32, 4-deep ring (gemm_256.hip), 1 block/CU
+      return mh_launch_gemm_256(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, g.bias, g.residual, g.ldr, g.flags,
+                                g.alpha, g.splits, g.tps, g.split_stride, stream);
     default: return MH_ERR_ARG;
   }
 }
@@ -342,7 +356,15 @@ static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t str
   GemmArgs g = g0;
   g.C = (void*)ws; g.ldc = g0.N; g.bias = nullptr; g.residual = nullptr; g.ldr = 0;
   g.flags = MH_GEMM_OUT_F32; g.alpha = 1.0f; g.splits = splits; g.tps = tps; g.split_stride = (long)g0.M * g0.N;
-  int rc = launch_gemm<0, 2, 128, 2>(g, stream);
+  int rc;
+  if (((g0.flags >> MH_GEMM_VARIANT_SHIFT) & 15) == 12)
+    rc = mh_launch_gemm_256(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, nullptr, nullptr, 0, g.flags, 1.0f,
+                            g.splits, g.tps, g.split_stride, stream);
+  else if (((g0.flags >> MH_GEMM_VARIANT_SHIFT) & 15) == 11)
+    rc = mh_launch_gemm_pp(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, nullptr, nullptr, 0, g.flags, 1.0f,
+                           g.splits, g.tps, g.split_stride, stream);
+  else
+    rc = launch_gemm<0, 2, 128, 2>(g, stream);
   if (rc) return rc;
   long gsz = ((long)g0.M * g0.N / 4 + 255) / 256;
   if (gsz > 4096) gsz = 4096;
@@ -374,6 +396,22 @@ static int auto_splits(int M, int N, int K) {
   return 1;
 }
 
+// 8-wave kernels run one workgroup per CU: pick the split count that best fills whole rounds of 256 workgroups
+static int big_tile_splits(int M, int N, int K, int tile_n) {
+  const long tiles = (long)((M + 255) / 256) * ((N + tile_n - 1) / tile_n);
+  const int kt = K / 64;
+  int best = 1;
+  double best_eff = 0.0;
+  for (int s = 1; s <= 4; ++s) {
+    if (s > 1 && kt / s < 16) break;
+    const long wg = tiles * s, rounds = (wg + 255) / 256;
+    // the reduce pass re-reads s fp32 slabs: its cost relative to the GEMM grows as s / K
+    const double eff = (double)wg / (double)(rounds * 256) / (s > 1 ? 1.0 + 600.0 * s / K : 1.0);
+    if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
+  }
+  return best;
+}
+
 extern "C" int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                                const float* bias, const float* residual, int ldr, int flags, float alpha,
                                hipStream_t stream) {
@@ -387,6 +425,23 @@ extern "C" int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   if (variant == 0 && M <= 16 && !(flags & (MH_GEMM_REGSTAGE | MH_GEMM_GELU)))
     return mh_launch_gemv(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, (flags & MH_GEMM_OUT_F32) ? 1 : 0, alpha,
                           stream);
+  if ((variant == 11 || variant == 12) && g_ws && (N % 4) == 0) {
+    const int best = big_tile_splits(M, N, K, variant == 12 ? 256 : 128);
+    if (best > 1 && (size_t)best * M * N * sizeof(float) <= g_ws_bytes) return run_splitk(g, best, g_ws, stream);
+  }
+  // automatic policy, large problems: the 256x256 kernel (gemm_256.hip) when it can put >= 128 workgroups on the
+  // chip with >= 1024 of K each -- +20..26 % over the 128x128 kernel on the step's LLaMA / ViT shapes, cold weights
+  // (profiles/r01_gemm_256.md); everything smaller stays on the 128x128 kernel, which co-schedules two workgroups
+  // per CU and so hides its own prologue / store tail
+  if (variant == 0 && !(flags & MH_GEMM_REGSTAGE) && M > 128) {
+    const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+    int s = (g_ws && (N % 4) == 0) ? big_tile_splits(M, N, K, 256) : 1;
+    if ((size_t)s * M * N * sizeof(float) > g_ws_bytes) s = 1;
+    if (tiles * s >= 128 && K / s >= 1024) {
+      g.flags |= 12 << MH_GEMM_VARIANT_SHIFT;
+      return s > 1 ? run_splitk(g, s, g_ws, stream) : dispatch(g, stream);
+    }
+  }
   if (variant == 0 && !(flags & MH_GEMM_REGSTAGE) && g_ws) {
     const int s = auto_splits(M, N, K);
     // the reduce reads `residual` and writes C element-wise, so C may alias residual (in-place accumulate)

@@ -1,0 +1,280 @@
+// K1 (large-tile variant): 256 x 256 x 32 block tile, 8 waves in two software-skewed groups, 4-deep LDS-DMA ring.
+//
+// Measured reasons for this shape (phase timelines from tools/gemm_pp_trace.py, knock-outs and steady-state rates in
+// profiles/r01_gemm_256.md):
+//   * the CU's vector-memory path moves 64 B/clk, i.e. one 1-KiB global_load_lds per 16 cycles.  A 128x128x64 tile
+//     stages 32 KiB per 512 MFMA-cycles/SIMD (100 % of that path at matrix peak), 256x128 needs 75 %, 256x256 50 %:
+//     only the 256x256 tile leaves the DMA path slack at the rates we are after;
+//   * a wave that issues LDS-DMA instructions in front of its MFMAs sits ~50 cycles per instruction on that path with
+//     the matrix pipe idle, so the prefetch is issued by the group that is in its fragment-read phase, never by
+//     the group that is issuing MFMAs;
+//   * LDS-DMA issue -> landed is 2-3k cycles under load, so the ring holds tiles t .. t+3 (three 32-deep tiles, i.e.
+//     ~3 x 1000 cycles of MFMA work, in flight).  BK = 32 is what lets four stages fit: 4 x 32 KiB = 128 KiB;
+//   * steady state is 1.45 PF/s on 4096^2 outputs (the vendor library's rate); what a K = 4096 launch loses is the
+//     fixed cost per workgroup (one workgroup per CU: nothing overlaps its prologue and store tail), hence the
+//     one-tile prologue wait and the LDS-transposed, full-line epilogue stores below.
+//
+// Waves: grp = wave >> 2 owns rows grp*128 .. +127, wc = wave & 3 owns columns wc*64 .. +63 (wave tile 128 x 64 =
+// 8 x 4 MFMA fragments, 128 accumulator registers; 12 ds_read_b128 feed 32 MFMAs).  One barrier per tile; inside
+// interval t
+//   group A:  reads(t)  prefetch(t+3)  MFMA(t)
+//   group B:  MFMA(t-1) [s_setprio 3]  reads(t)  prefetch(t+3)
+// Each SIMD holds one wave of each group, so its matrix pipe sees B's 32 MFMAs, then A's, back to back, with the
+// other wave's LDS reads / DMA issue underneath.  B's MFMAs outrank A's (priority, then age) so B drains first and
+// its reads hide under A's MFMAs.  Tile t+3 goes into the stage that was read during interval t-1; a share issued in
+// interval t is retired by a counted vmcnt (two younger shares stay in flight) before barrier t+2, and first read
+// after it.
+//
+// LDS image: rows of 64 B (32 bf16), four 16-B chunks per row, physical chunk = logical ^ g(row>>2 & 3) with
+// g = {0,2,3,1}.  ds_read_b128 is served in lane groups {0-3,12-15,20-27}, ...: rows {0-3,12-15} at chunk c and
+// rows {4-11} at chunk c^1 must fall on 16 distinct 16-B slots of the 256-B bank row; slot = (row&3)*4 + physical
+// chunk, which needs {g0, g3, 1^g1, 1^g2} and {g1, g2, 1^g0, 1^g3} each distinct -- the identity map (chunk ^
+// row>>2) is 2-way conflicted, {0,2,3,1} is conflict-free (SQ_LDS_BANK_CONFLICT = 0 measured).  LDS-DMA writes are
+// lane-linear, so the same permutation is applied to the per-lane global source address.
+#include "common.h"
+#include <cstdlib>
+
+#define G2_BM 256
+#define G2_BN 256
+#define G2_BK 32
+#define G2_NST 4
+#define G2_A_BYTES (G2_BM * G2_BK * 2)   // 16 KiB
+#define G2_B_BYTES (G2_BN * G2_BK * 2)   // 16 KiB
+#define G2_STAGE (G2_A_BYTES + G2_B_BYTES)
+
+#define MH_GEMM_OUT_F32 1
+#define MH_GEMM_GELU 2
+
+typedef __attribute__((address_space(3))) void lds_void_t;
+typedef const __attribute__((address_space(1))) void gbl_void_t;
+
+__device__ __forceinline__ int g2_perm(int row) { return (0x78 >> (((row >> 2) & 3) * 2)) & 3; }   // {0,2,3,1}
+__device__ __forceinline__ int g2_off(int row, int chunk) { return row * 64 + ((chunk ^ g2_perm(row)) << 4); }
+
+// TRACE build: wave 0 of each group in workgroup 0 stamps s_memtime at the phase boundaries (slot 7: 100 MHz counter)
+#define G2_STAMP(slot)                                                                        \
+  if (TRACE) {                                                                                \
+    if (trace && blockIdx.x == 0 && blockIdx.y == 0 && wc == 0 && lane == 0 && t < 64)        \
+      trace[(grp * 64 + t) * 8 + (slot)] = (slot) == 7 ? (long long)__builtin_amdgcn_s_memrealtime() \
+                                                       : (long long)__builtin_amdgcn_s_memtime();   \
+  }
+
+template <int N>
+__device__ __forceinline__ void g2_wait_vm() {
+  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+}
+__device__ __forceinline__ void g2_wait_younger(int younger_tiles) {   // 4 LDS-DMA instructions per tile share
+  if (younger_tiles >= 3) g2_wait_vm<12>();
+  else if (younger_tiles == 2) g2_wait_vm<8>();
+  else if (younger_tiles == 1) g2_wait_vm<4>();
+  else g2_wait_vm<0>();
+}
+
+template <bool TRACE>
+__global__ __launch_bounds__(512, 2) void gemm_256_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
+                                                          void* Cv, const float* __restrict__ bias, const float* res,
+                                                          int M, int N, int K, int lda, int ldb, int ldc, int ldr,
+                                                          int flags, float alpha, int tiles_m, int kt_per_split,
+                                                          long split_stride, long long* trace) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 stages][A 16K | B 16K]; reused by the epilogue
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2, wc = wave & 3;
+  const int lr = lane & 15, lg = lane >> 4;
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  // consecutive tiles (one XCD's concurrent 32 workgroups) walk 8 tile-rows before the next tile-column: an 8 x 4
+  // patch re-uses each A panel 4x and each B panel 8x out of that XCD's L2 instead of 32 A panels against one B panel
+  const int tiles_n = nwg / tiles_m;
+  const int per_group = 8 * tiles_n;
+  const int first_m = (lid / per_group) * 8;
+  const int gsz = (tiles_m - first_m) < 8 ? (tiles_m - first_m) : 8;
+  const int tm = first_m + (lid % per_group) % gsz, tn = (lid % per_group) / gsz;
+  const int m0 = tm * G2_BM, n0 = tn * G2_BN;
+
+  // staging shares: 1024 chunks of 16 B per operand tile -> 2 + 2 LDS-DMA instructions per thread per tile
+  const bf16_t* gA[2];
+  const bf16_t* gB[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = i * 512 + tid;
+    const int row = c >> 2, lc = (c & 3) ^ g2_perm(row);
+    int ra = m0 + row, rb = n0 + row;
+    ra = ra < M ? ra : M - 1;
+    rb = rb < N ? rb : N - 1;
+    gA[i] = A + (size_t)ra * lda + lc * 8;
+    gB[i] = B + (size_t)rb * ldb + lc * 8;
+  }
+
+  float4_t acc[8][4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (float4_t){0.f, 0.f, 0.f, 0.f};
+
+  const int nt_all = K / G2_BK;
+  const int kt0 = blockIdx.y * kt_per_split;
+  const int nt = (nt_all - kt0) < kt_per_split ? (nt_all - kt0) : kt_per_split;
+  if (gridDim.y > 1) Cv = reinterpret_cast<float*>(Cv) + blockIdx.y * split_stride;
+
+  auto issue = [&](int t) {
+    char* sA = smem + (t & 3) * G2_STAGE;
+    char* sB = sA + G2_A_BYTES;
+    const int k0 = (kt0 + t) * G2_BK;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(gA[i] + k0), (lds_void_t*)(sA + (i * 512 + wave * 64) * 16), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(gB[i] + k0), (lds_void_t*)(sB + (i * 512 + wave * 64) * 16), 16, 0, 0);
+  };
+
+  // prologue: put four tiles in flight but start on the first one (every CU is in its prologue at the same time, so
+  // waiting for all four costs the whole 32 MiB burst at HBM rate before any MFMA issues)
+#pragma unroll
+  for (int t = 0; t < G2_NST; ++t)
+    if (t < nt) issue(t);
+  g2_wait_younger(nt - 1);
+  __builtin_amdgcn_s_barrier();                       // tile 0 visible
+
+  // per-lane fragment byte offsets inside a stage (row & chunk permutation are tile-invariant)
+  int offA[8], offB[4];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) offA[i] = g2_off(grp * 128 + i * 16 + lr, lg);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) offB[j] = G2_A_BYTES + g2_off(wc * 64 + j * 16 + lr, lg);
+
+  short8_t af[8], bfr[4];
+  auto mfma_block = [&]() {
+    if (grp == 1) __builtin_amdgcn_s_setprio(3);
+    else __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  for (int t = 0; t < nt; ++t) {
+    G2_STAMP(0)
+    G2_STAMP(7)
+    if (grp == 1 && t > 0) mfma_block();               // fragments of tile t-1, read in the previous interval
+    G2_STAMP(1)
+    __builtin_amdgcn_sched_barrier(0);
+    const char* st = smem + (t & 3) * G2_STAGE;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = *reinterpret_cast<const short8_t*>(st + offB[j]);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) af[i] = *reinterpret_cast<const short8_t*>(st + offA[i]);
+    if (t >= 1 && t + 3 < nt) issue(t + 3);            // behind the reads: DMA issue overlaps the LDS latency
+    G2_STAMP(2)
+    __builtin_amdgcn_sched_barrier(0);
+    if (grp == 0) mfma_block();
+    G2_STAMP(3)
+    g2_wait_younger(nt - t - 2 < 2 ? nt - t - 2 : 2);  // tile t+1's share has landed (tiles t+2, t+3 may be in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // my reads of tile t are done (WAR on its stage)
+    G2_STAMP(4)
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    G2_STAMP(5)
+  }
+  if (grp == 1 && nt > 0) mfma_block();
+
+  // ---- epilogue.  Every LDS-DMA has been retired and every fragment read is done (last barrier), so the ring is
+  // free: each wave transposes its 128 x 64 fp32 tile through a private 16-KiB slice, 64 rows at a time, so that the
+  // global stores are whole rows -- 16 lanes x 8 B (bf16) or x 16 B (fp32) = one or two full 128-B lines per row --
+  // instead of the MFMA layout's 32-B fragments (the store tail was ~1/3 of a K = 4096 launch).  Bias / GELU /
+  // residual are applied on the way out, where a lane holds 4 consecutive columns of one row.
+  const bool out_f32 = flags & MH_GEMM_OUT_F32;
+  const bool do_gelu = flags & MH_GEMM_GELU;
+  char* ep = smem + wave * 16384;                      // [64 rows][16 chunks of 16 B], chunk ^= row & 15
+  const int er = lane >> 4, ec = lane & 15;            // write-out: 4 rows per pass, lane owns columns ec*4 .. +3
+  const int ncol = n0 + wc * 64 + ec * 4;
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int ii = 0; ii < 4; ++ii) {
+      const int i = h * 4 + ii;
+      const int row = ii * 16 + lr;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int c = j * 4 + lg;
+        *reinterpret_cast<float4_t*>(ep + row * 256 + ((c ^ (row & 15)) << 4)) =
+            (float4_t){acc[i][j][0] * alpha, acc[i][j][1] * alpha, acc[i][j][2] * alpha, acc[i][j][3] * alpha};
+      }
+    }
+    // the slice is private to the wave: program order + the compiler's lgkmcnt wait are the only ordering needed
+#pragma unroll 4
+    for (int p = 0; p < 16; ++p) {
+      const int row = p * 4 + er;
+      const int m = m0 + grp * 128 + h * 64 + row;
+      const float4_t v4 = *reinterpret_cast<const float4_t*>(ep + row * 256 + ((ec ^ (row & 15)) << 4));
+      if (m >= M || ncol >= N) continue;
+      float v[4] = {v4[0], v4[1], v4[2], v4[3]};
+      if (ncol + 3 < N) {
+        if (bias) {
+          const float4_t b4 = *reinterpret_cast<const float4_t*>(bias + ncol);
+          v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+        }
+        if (do_gelu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (res) {
+          const float4_t r4 = *reinterpret_cast<const float4_t*>(res + (size_t)m * ldr + ncol);
+          v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
+        }
+        if (out_f32) {
+          *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(Cv) + (size_t)m * ldc + ncol) =
+              (float4_t){v[0], v[1], v[2], v[3]};
+        } else {
+          uint2 pk;
+          pk.x = pack_bf2(v[0], v[1]);
+          pk.y = pack_bf2(v[2], v[3]);
+          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (size_t)m * ldc + ncol) = pk;
+        }
+      } else {
+        for (int e = 0; e < 4 && ncol + e < N; ++e) {
+          float x = v[e];
+          if (bias) x += bias[ncol + e];
+          if (do_gelu) x = gelu_erf(x);
+          if (res) x += res[(size_t)m * ldr + ncol + e];
+          if (out_f32) reinterpret_cast<float*>(Cv)[(size_t)m * ldc + ncol + e] = x;
+          else reinterpret_cast<bf16_t*>(Cv)[(size_t)m * ldc + ncol + e] = f2bf(x);
+        }
+      }
+    }
+  }
+}
+
+static long long* g2_trace = nullptr;
+extern "C" void mhdbg_set_gemm256_trace(void* p) { g2_trace = (long long*)p; }   // debug hook, not part of the ABI
+
+// tps / split_stride as in gemm.hip (tps in 64-deep K tiles)
+int mh_launch_gemm_256(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                       const float* bias, const float* residual, int ldr, int flags, float alpha, int splits, int tps,
+                       long split_stride, hipStream_t stream) {
+  const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
+  const size_t shmem = G2_NST * G2_STAGE;   // 128 KiB -> one 8-wave workgroup per CU
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)gemm_256_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    (void)hipFuncSetAttribute((const void*)gemm_256_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+    attr_set = true;
+  }
+  const dim3 grid(tiles_m * tiles_n, splits), block(512);
+  if (g2_trace)
+    hipLaunchKernelGGL((gemm_256_kernel<true>), grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)B, C, bias,
+                       residual, M, N, K, lda, ldb, ldc, ldr, flags, alpha, tiles_m, tps * 2, split_stride, g2_trace);
+  else
+    hipLaunchKernelGGL((gemm_256_kernel<false>), grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)B, C, bias,
+                       residual, M, N, K, lda, ldb, ldc, ldr, flags, alpha, tiles_m, tps * 2, split_stride, nullptr);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}

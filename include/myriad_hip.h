@@ -35,6 +35,11 @@ typedef struct ihipStream_t* mh_stream_t; /* == hipStream_t */
 int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                     const float* bias, const float* residual, int ldr, int flags, float alpha, mh_stream_t s);
 
+/* Which kernel mh_gemm_bf16_nt will launch for this shape and with how many K splits (splits > 1 adds one
+ * fixed-order reduce launch): *kernel = 0 weight-streaming gemv (M <= 16), 1 = 128x128x64 tile (gemm_nt_kernel),
+ * 2 = 256x256x32 tile (gemm_256_kernel).  For profilers and benchmarks that attribute time per kernel. */
+int mh_gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits);
+
 /* Scratch for the automatic split-K path of mh_gemm_bf16_nt (used for shapes whose tile count under-fills the
  * 256 CUs).  The caller owns the buffer; pass NULL to disable.  Not needed for correctness. */
 int mh_set_workspace(void* ptr, long bytes);
@@ -140,6 +145,12 @@ int mh_copy3d_bf16(const void* src, long src_bstride, long lds, void* dst, long 
  * hipGraph and replayed per token (modeling_llama.py:190-195 concatenates; the cache is written in place). */
 int mh_kv_append_bf16(const void* src, long ld_src, void* cache, long cache_bstride, long ld_cache, const int* pos_dev,
                       int B, int cols, mh_stream_t s);
+/* One decode token per batch row: rotary on q (in place) and on k, then k|v written into cache row pos_dev[0]
+ * (modeling_llama.py:186-195: apply_rotary_pos_emb + cat with past_key_value) -- rope + append in one launch.
+ * qkv [B, ld] bf16 = [q | k | v] with W = n_heads*head_dim columns each; cache row layout [k | v]. */
+int mh_rope_kv_append(void* qkv, long ld, int n_heads, int head_dim, const int* pos, const float* cos_tab,
+                      const float* sin_tab, void* cache, long cache_bstride, long ld_cache, const int* pos_dev, int B,
+                      mh_stream_t s);
 int mh_add_i32(int* x, int n, int delta, mh_stream_t s);
 /* K14 patch embedding operand (eva_vit.py:196-204): NCHW f32 image -> [B*np, Kpad] bf16 in (c,iy,ix) order */
 int mh_patchify_nchw(const float* img, void* out, int B, int C, int H, int W, int P, int Kpad, mh_stream_t s);

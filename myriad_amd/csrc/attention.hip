@@ -414,6 +414,97 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------- C ABI
+// ---- Sq == 1 (KV-cache decode, modeling_llama.py:197-222 with past_key_value): one 4-wave workgroup per (b, h).
+// The MFMA tile kernel above spends ~19 us on this shape (one 64-row query tile with a single live row, K/V staged
+// through LDS tile by tile); here the work is what it is -- stream len x D of K, then len x D of V, once:
+//   scores: 16 lanes share a key (16 B of the row each), 4 keys per wave pass, 16 per workgroup pass -> LDS
+//   softmax: every wave reduces the LDS scores itself (len <= a few hundred)
+//   PV: lane owns two head dims, waves take keys round-robin, 8 independent 256-B row loads in flight per wave
+// fp32 throughout (the tile kernel rounds P to bf16 for its MFMA), output rounded to bf16 once.
+__global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
+  extern __shared__ float dsm[];                 // [Sk] scores, then [4][128] partial outputs
+  const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int len = p.kv_len ? p.kv_len[b] : p.Sk;
+  len = len < p.Sk ? len : p.Sk;
+  const int D = p.D;
+  const bf16_t* qp = p.q + (size_t)b * p.q_bs + h * D;
+  const bf16_t* kp = p.k + (size_t)b * p.k_bs + h * D;
+  const bf16_t* vp = p.v + (size_t)b * p.v_bs + h * D;
+  float* sc = dsm;
+  float* part = dsm + ((p.Sk + 63) & ~63);
+  // phase 1: scores
+  const int sub = lane & 15, kq = lane >> 4;     // 16 lanes per key, dims sub*8 .. +7
+  float qf[8];
+  const bool dim_ok = sub * 8 < D;
+  {
+    short8_t qv = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (dim_ok) qv = *reinterpret_cast<const short8_t*>(qp + sub * 8);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) qf[e] = bf2f((bf16_t)qv[e]) * p.scale;
+  }
+  for (int j0 = 0; j0 < len; j0 += 16) {
+    const int j = j0 + wave * 4 + kq;
+    float s = 0.f;
+    if (j < len && dim_ok) {
+      const short8_t kv = *reinterpret_cast<const short8_t*>(kp + (size_t)j * p.ldk + sub * 8);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += qf[e] * bf2f((bf16_t)kv[e]);
+    }
+    s += __shfl_xor(s, 1, 64);
+    s += __shfl_xor(s, 2, 64);
+    s += __shfl_xor(s, 4, 64);
+    s += __shfl_xor(s, 8, 64);
+    if (sub == 0 && j < len) sc[j] = s;
+  }
+  __syncthreads();
+  // phase 2: softmax statistics (each wave for itself)
+  float mx = -INFINITY;
+  for (int j = lane; j < len; j += 64) mx = fmaxf(mx, sc[j]);
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int j = lane; j < len; j += 64) sum += __expf(sc[j] - mx);
+  sum = wave_sum(sum);
+  // phase 3: o = sum_j p_j V[j]; lane owns dims 2*lane, 2*lane+1; wave w takes keys w, w+4, ...
+  float o0 = 0.f, o1 = 0.f;
+  const bool own = 2 * lane < D;
+  int j = wave;
+  for (; j + 28 < len; j += 32) {
+    unsigned vv[8];
+    float pj[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      vv[u] = own ? *reinterpret_cast<const unsigned*>(vp + (size_t)(j + 4 * u) * p.ldv + 2 * lane) : 0u;
+      pj[u] = __expf(sc[j + 4 * u] - mx);
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      o0 += pj[u] * bf2f((bf16_t)(vv[u] & 0xffffu));
+      o1 += pj[u] * bf2f((bf16_t)(vv[u] >> 16));
+    }
+  }
+  for (; j < len; j += 4) {
+    const unsigned vv = own ? *reinterpret_cast<const unsigned*>(vp + (size_t)j * p.ldv + 2 * lane) : 0u;
+    const float pj = __expf(sc[j] - mx);
+    o0 += pj * bf2f((bf16_t)(vv & 0xffffu));
+    o1 += pj * bf2f((bf16_t)(vv >> 16));
+  }
+  part[wave * 128 + 2 * lane] = o0;
+  part[wave * 128 + 2 * lane + 1] = o1;
+  __syncthreads();
+  if (wave == 0 && own) {
+    const float inv = len > 0 ? 1.f / sum : 0.f;
+    float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      r0 += part[w * 128 + 2 * lane];
+      r1 += part[w * 128 + 2 * lane + 1];
+    }
+    *reinterpret_cast<unsigned*>(p.o + (size_t)b * p.o_bs + h * D + 2 * lane) = pack_bf2(r0 * inv, r1 * inv);
+  }
+  if (p.lse && tid == 0) p.lse[(size_t)b * p.H + h] = len > 0 ? mx + __logf(sum) : -INFINITY;
+}
+
 static int check_common(const AttnParams& p) {
   if (p.D % 8 || p.D > 128 || p.D <= 0) return MH_ERR_UNSUPPORTED;
   if (p.ldq % 8 || p.ldk % 8 || p.ldv % 8) return MH_ERR_ARG;
@@ -466,6 +557,12 @@ extern "C" int mh_attn_fwd(const void* q, const void* k, const void* v, void* o,
   int rc = check_common(p);
   if (rc) return rc;
   if (ldo % 4) return MH_ERR_ARG;
+  if (Sq == 1 && !bias && Sk <= 8192 && (ldv % 2) == 0) {   // KV-cache decode (causal or not: the one query sees every valid key)
+    const size_t sh = (((size_t)Sk + 63) & ~(size_t)63) * 4 + 4 * 128 * 4;
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(B * H), dim3(256), sh, stream, p);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+  }
   if (D <= 64) return launch_fwd<64>(p, stream);
   if (D <= 96) return launch_fwd<96>(p, stream);
   return launch_fwd<128>(p, stream);

@@ -539,6 +539,59 @@ extern "C" int mh_kv_append_bf16(const void* src, long ld_src, void* cache, long
   return MH_OK;
 }
 
+// ---- decode token: rotary on q (in place) and k, then k|v straight into the cache row pos_dev[0] -- one launch
+// instead of rope + kv_append (modeling_llama.py:186-195).  qkv: [B, 3W] bf16 = [q | k | v], W = H*d; cache row
+// layout [k | v].  Same arithmetic as rope_kernel (fp32 rotate-half, one rounding to bf16).
+__global__ void rope_kv_append_kernel(bf16_t* qkv, long ld, int H, int d, const int* __restrict__ pos,
+                                      const float* __restrict__ cs, const float* __restrict__ sn,
+                                      bf16_t* __restrict__ cache, long cache_bs, long ld_cache,
+                                      const int* __restrict__ pos_dev, int B) {
+  const int half = d >> 1, W = H * d;
+  const int rope_items = 2 * H * (half >> 2);      // q heads then k heads, 4 pairs per item
+  const int per_tok = rope_items + (W >> 3);       // + v copy, 8 elements per item
+  const long total = (long)B * per_tok;
+  const long row = pos_dev[0];
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long b = it / per_tok;
+    const int rem = (int)(it - b * per_tok);
+    bf16_t* src = qkv + b * ld;
+    bf16_t* crow = cache + b * cache_bs + row * ld_cache;
+    if (rem >= rope_items) {
+      const int c = (rem - rope_items) * 8;
+      *reinterpret_cast<short8_t*>(crow + W + c) = *reinterpret_cast<const short8_t*>(src + 2 * W + c);
+      continue;
+    }
+    const int h = rem / (half >> 2), i = (rem % (half >> 2)) * 4;   // h in [0, 2H): q heads, then k heads
+    bf16_t* p = src + h * d + i;
+    const int ps = pos[b];
+    const float4_t c4 = *reinterpret_cast<const float4_t*>(cs + (size_t)ps * half + i);
+    const float4_t s4 = *reinterpret_cast<const float4_t*>(sn + (size_t)ps * half + i);
+    const short4_t a = *reinterpret_cast<const short4_t*>(p);
+    const short4_t bb = *reinterpret_cast<const short4_t*>(p + half);
+    short4_t oa, ob;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float x1 = bf2f((bf16_t)a[e]), x2 = bf2f((bf16_t)bb[e]);
+      oa[e] = (short)f2bf(x1 * c4[e] - x2 * s4[e]);
+      ob[e] = (short)f2bf(x2 * c4[e] + x1 * s4[e]);
+    }
+    bf16_t* dst = h < H ? p : crow + (h - H) * d + i;               // q in place, k into the cache
+    *reinterpret_cast<short4_t*>(dst) = oa;
+    *reinterpret_cast<short4_t*>(dst + half) = ob;
+  }
+}
+extern "C" int mh_rope_kv_append(void* qkv, long ld, int n_heads, int head_dim, const int* pos, const float* cos_tab,
+                                 const float* sin_tab, void* cache, long cache_bstride, long ld_cache,
+                                 const int* pos_dev, int B, hipStream_t stream) {
+  if (B <= 0) return MH_OK;
+  if (head_dim % 8 || ld % 8 || ld_cache % 8 || cache_bstride % 8) return MH_ERR_ARG;
+  const long items = (long)B * (2L * n_heads * (head_dim / 8) + (long)n_heads * head_dim / 8);
+  hipLaunchKernelGGL(rope_kv_append_kernel, dim3(ew_grid(items)), dim3(EW_NT), 0, stream, (bf16_t*)qkv, ld, n_heads,
+                     head_dim, pos, cos_tab, sin_tab, (bf16_t*)cache, cache_bstride, ld_cache, pos_dev, B);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
 __global__ void add_i32_kernel(int* x, int n, int delta) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) x[i] += delta;

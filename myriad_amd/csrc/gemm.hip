@@ -412,6 +412,37 @@ static int big_tile_splits(int M, int N, int K, int tile_n) {
   return best;
 }
 
+// The automatic policy (flags carry no variant): which kernel runs and with how many K splits.
+//   kernel 0: gemv.hip weight streaming (M <= 16: decode)
+//   kernel 2: gemm_256.hip 256x256 tile, when it can put >= 128 workgroups on the chip with >= 1024 of K each
+//             (+20..26 % over the 128x128 kernel on the step's LLaMA / ViT shapes, cold weights,
+//             profiles/r01_gemm_256.md)
+//   kernel 1: the 128x128 kernel for everything smaller -- it co-schedules two workgroups per CU and so hides its
+//             own prologue / store tail, which the one-workgroup-per-CU 256x256 kernel cannot
+static void gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits) {
+  *kernel = 1;
+  *splits = 1;
+  if (M <= 16 && !(flags & (MH_GEMM_REGSTAGE | MH_GEMM_GELU))) { *kernel = 0; return; }
+  if (flags & MH_GEMM_REGSTAGE) return;
+  const bool can_split = g_ws && (N % 4) == 0;
+  if (M > 128) {
+    const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
+    int s = can_split ? big_tile_splits(M, N, K, 256) : 1;
+    if ((size_t)s * M * N * sizeof(float) > g_ws_bytes) s = 1;
+    if (tiles * s >= 128 && K / s >= 1024) { *kernel = 2; *splits = s; return; }
+  }
+  if (can_split) {
+    const int s = auto_splits(M, N, K);
+    if (s > 1 && (size_t)s * M * N * sizeof(float) <= g_ws_bytes) *splits = s;
+  }
+}
+
+extern "C" int mh_gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits) {
+  if (!kernel || !splits || M <= 0 || N <= 0 || K <= 0 || ((flags >> MH_GEMM_VARIANT_SHIFT) & 15)) return MH_ERR_ARG;
+  gemm_plan(M, N, K, flags, kernel, splits);
+  return MH_OK;
+}
+
 extern "C" int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                                const float* bias, const float* residual, int ldr, int flags, float alpha,
                                hipStream_t stream) {
@@ -421,31 +452,20 @@ extern "C" int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   if ((ldc % 4) != 0 || (residual && (ldr % 4) != 0)) return MH_ERR_ARG;
   GemmArgs g = {A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, flags, alpha, 1, K / 64, 0L};
   const int variant = (flags >> MH_GEMM_VARIANT_SHIFT) & 15;
-  // decode / tiny-M: weight-streaming kernel (gemv.hip) instead of the 128-row training tile
-  if (variant == 0 && M <= 16 && !(flags & (MH_GEMM_REGSTAGE | MH_GEMM_GELU)))
-    return mh_launch_gemv(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, (flags & MH_GEMM_OUT_F32) ? 1 : 0, alpha,
-                          stream);
+  if (variant == 0) {
+    int kernel, splits;
+    gemm_plan(M, N, K, flags, &kernel, &splits);
+    if (kernel == 0)
+      return mh_launch_gemv(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, (flags & MH_GEMM_OUT_F32) ? 1 : 0,
+                            alpha, stream);
+    if (kernel == 2) g.flags |= 12 << MH_GEMM_VARIANT_SHIFT;
+    // the split-K reduce reads `residual` and writes C element-wise, so C may alias residual (in-place accumulate)
+    return splits > 1 ? run_splitk(g, splits, g_ws, stream) : dispatch(g, stream);
+  }
+  // forced variants (A/B tools): the 8-wave kernels still pick their own split count
   if ((variant == 11 || variant == 12) && g_ws && (N % 4) == 0) {
     const int best = big_tile_splits(M, N, K, variant == 12 ? 256 : 128);
     if (best > 1 && (size_t)best * M * N * sizeof(float) <= g_ws_bytes) return run_splitk(g, best, g_ws, stream);
-  }
-  // automatic policy, large problems: the 256x256 kernel (gemm_256.hip) when it can put >= 128 workgroups on the
-  // chip with >= 1024 of K each -- +20..26 % over the 128x128 kernel on the step's LLaMA / ViT shapes, cold weights
-  // (profiles/r01_gemm_256.md); everything smaller stays on the 128x128 kernel, which co-schedules two workgroups
-  // per CU and so hides its own prologue / store tail
-  if (variant == 0 && !(flags & MH_GEMM_REGSTAGE) && M > 128) {
-    const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
-    int s = (g_ws && (N % 4) == 0) ? big_tile_splits(M, N, K, 256) : 1;
-    if ((size_t)s * M * N * sizeof(float) > g_ws_bytes) s = 1;
-    if (tiles * s >= 128 && K / s >= 1024) {
-      g.flags |= 12 << MH_GEMM_VARIANT_SHIFT;
-      return s > 1 ? run_splitk(g, s, g_ws, stream) : dispatch(g, stream);
-    }
-  }
-  if (variant == 0 && !(flags & MH_GEMM_REGSTAGE) && g_ws) {
-    const int s = auto_splits(M, N, K);
-    // the reduce reads `residual` and writes C element-wise, so C may alias residual (in-place accumulate)
-    if (s > 1 && (size_t)s * M * N * sizeof(float) <= g_ws_bytes) return run_splitk(g, s, g_ws, stream);
   }
   return dispatch(g, stream);
 }

@@ -4,17 +4,19 @@
 // Vicuna-7B, reference modeling_llama.py:184-231 with the KV cache): HBM-bound, 2.1 ms/token at 6.3 TB/s.  The
 // 128x128 training tile starves here (N = 4096 gives 32 workgroups for 256 CUs and nothing hides HBM latency), so
 // this kernel makes the WEIGHT stream the only thing that matters:
-//   * a workgroup owns 16 output columns (16 weight rows), its 4 waves split K (interleaved 32-deep steps) and are
-//     reduced through LDS at the end  ->  N/16 workgroups (768 for qkv, 1376 for gate|up), ~1k waves streaming;
-//   * every lane loads its weight fragment straight from global memory in MFMA B-operand layout (16 B/lane, deep
-//     unroll, no LDS round trip -- the operand is read once and never shared between waves);
+//   * a workgroup owns 16 output columns (16 weight rows), its 4 waves split K and are reduced through LDS at the
+//     end  ->  N/16 workgroups (768 for qkv, 1376 for gate|up), ~1k waves streaming;
+//   * every lane loads its weight fragment straight from global memory in MFMA B-operand layout (no LDS round
+//     trip -- the operand is read once and never shared between waves).  The dot product does not care which k a
+//     lane holds as long as both operands agree, so lane (row, lg) takes 32 CONTIGUOUS bytes (k = 16*lg .. +15 of a
+//     64-deep step, two MFMAs): the four lanes of a row then cover one whole 128-B line per step instead of half of
+//     one (MODE 0, the first version, measured 3.9-4.2 TB/s);
 //   * the activation rows (<= 16 x K bf16, L2-resident) are read as the A operand of v_mfma_f32_16x16x32_bf16, so
 //     one MFMA retires 1 KiB of weights: the matrix pipe is idle-cheap and exact-fp32 accumulation comes for free.
 #include "common.h"
+#include <cstdlib>
 
-#define GV_NW 4
-#define GV_UNROLL 8
-
+template <int MODE, int UNROLL, int GV_NW>
 __global__ __launch_bounds__(GV_NW * 64) void gemv_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B,
                                                           void* __restrict__ Cv, const float* __restrict__ bias,
                                                           const float* res, int M, int N, int K, int lda, int ldb,
@@ -26,28 +28,62 @@ __global__ __launch_bounds__(GV_NW * 64) void gemv_kernel(const bf16_t* __restri
   int nrow = n0 + lr;
   nrow = nrow < N ? nrow : N - 1;
   const int mrow = lr < M ? lr : M - 1;          // rows >= M duplicate the last row; their results are never stored
-  const bf16_t* wp = B + (size_t)nrow * ldb + lg * 8;
-  const bf16_t* xp = A + (size_t)mrow * lda + lg * 8;
   float4_t acc = (float4_t){0.f, 0.f, 0.f, 0.f};
-  const int nsteps = K / 32;
-  // wave w takes steps w, w+4, w+8, ...; GV_UNROLL independent loads in flight per lane
-  int s = wave;
-  for (; s + (GV_UNROLL - 1) * GV_NW < nsteps; s += GV_UNROLL * GV_NW) {
-    short8_t wv[GV_UNROLL], xv[GV_UNROLL];
+  if (MODE == 0) {
+    const bf16_t* wp = B + (size_t)nrow * ldb + lg * 8;
+    const bf16_t* xp = A + (size_t)mrow * lda + lg * 8;
+    const int nsteps = K / 32;
+    // wave w takes 32-deep steps w, w+4, w+8, ...; UNROLL independent loads in flight per lane
+    int s = wave;
+    for (; s + (UNROLL - 1) * GV_NW < nsteps; s += UNROLL * GV_NW) {
+      short8_t wv[UNROLL], xv[UNROLL];
 #pragma unroll
-    for (int u = 0; u < GV_UNROLL; ++u) {
-      const int k = (s + u * GV_NW) * 32;
-      wv[u] = __builtin_nontemporal_load(reinterpret_cast<const short8_t*>(wp + k));   // streamed once: don't pollute L2
-      xv[u] = *reinterpret_cast<const short8_t*>(xp + k);
+      for (int u = 0; u < UNROLL; ++u) {
+        const int k = (s + u * GV_NW) * 32;
+        wv[u] = __builtin_nontemporal_load(reinterpret_cast<const short8_t*>(wp + k));   // streamed once
+        xv[u] = *reinterpret_cast<const short8_t*>(xp + k);
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xv[u], wv[u], acc, 0, 0, 0);
     }
+    for (; s < nsteps; s += GV_NW) {
+      const int k = s * 32;
+      const short8_t wv = *reinterpret_cast<const short8_t*>(wp + k);
+      const short8_t xv = *reinterpret_cast<const short8_t*>(xp + k);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xv, wv, acc, 0, 0, 0);
+    }
+  } else {
+    // 64-deep steps, lane holds k = 16*lg .. 16*lg+15 (32 contiguous bytes); wave w owns the contiguous K quarter
+    // [w*K/4, (w+1)*K/4) rounded to steps, so each wave walks 16 rows line by line
+    const bf16_t* wp = B + (size_t)nrow * ldb + lg * 16;
+    const bf16_t* xp = A + (size_t)mrow * lda + lg * 16;
+    const int nsteps = K / 64;
+    const int per = (nsteps + GV_NW - 1) / GV_NW;
+    int s = wave * per;
+    const int s_end = (s + per) < nsteps ? (s + per) : nsteps;
+    for (; s + UNROLL <= s_end; s += UNROLL) {
+      short8_t w0[UNROLL], w1[UNROLL], x0[UNROLL], x1[UNROLL];
 #pragma unroll
-    for (int u = 0; u < GV_UNROLL; ++u) acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xv[u], wv[u], acc, 0, 0, 0);
-  }
-  for (; s < nsteps; s += GV_NW) {
-    const int k = s * 32;
-    const short8_t wv = *reinterpret_cast<const short8_t*>(wp + k);
-    const short8_t xv = *reinterpret_cast<const short8_t*>(xp + k);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xv, wv, acc, 0, 0, 0);
+      for (int u = 0; u < UNROLL; ++u) {
+        const int k = (s + u) * 64;
+        w0[u] = __builtin_nontemporal_load(reinterpret_cast<const short8_t*>(wp + k));
+        w1[u] = __builtin_nontemporal_load(reinterpret_cast<const short8_t*>(wp + k + 8));
+        x0[u] = *reinterpret_cast<const short8_t*>(xp + k);
+        x1[u] = *reinterpret_cast<const short8_t*>(xp + k + 8);
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0[u], w0[u], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1[u], w1[u], acc, 0, 0, 0);
+      }
+    }
+    for (; s < s_end; ++s) {
+      const int k = s * 64;
+      const short8_t w0 = *reinterpret_cast<const short8_t*>(wp + k), w1 = *reinterpret_cast<const short8_t*>(wp + k + 8);
+      const short8_t x0 = *reinterpret_cast<const short8_t*>(xp + k), x1 = *reinterpret_cast<const short8_t*>(xp + k + 8);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, w0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w1, acc, 0, 0, 0);
+    }
   }
   // D layout: row m = 4*lg + r, col n = lr.  Cross-wave K reduction through LDS, then wave 0 finishes.
 #pragma unroll
@@ -74,8 +110,26 @@ __global__ __launch_bounds__(GV_NW * 64) void gemv_kernel(const bf16_t* __restri
 // called from mh_gemm_bf16_nt for M <= 16 (no GELU epilogue on this path)
 int mh_launch_gemv(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                    const float* bias, const float* residual, int ldr, int out_f32, float alpha, hipStream_t stream) {
-  hipLaunchKernelGGL(gemv_kernel, dim3((N + 15) / 16), dim3(GV_NW * 64), 0, stream, (const bf16_t*)A, (const bf16_t*)B,
-                     C, bias, residual, M, N, K, lda, ldb, ldc, ldr, out_f32, alpha);
+  static int mode = -1;
+  if (mode < 0) {
+    const char* e = getenv("MYRIAD_GEMV_MODE");   // debug: A/B of the load patterns
+    mode = e ? atoi(e) : 1;
+  }
+  static int nw_small = -1;
+  if (nw_small < 0) {
+    const char* e = getenv("MYRIAD_GEMV_NW");     // debug: waves per workgroup when N/16 under-fills the chip
+    nw_small = e ? atoi(e) : 8;                   // N = 4096, K = 11008: 4.12 vs 3.86 TB/s with 8 waves
+  }
+  const dim3 grid((N + 15) / 16);
+#define GV_LAUNCH(MODE, UNR, NW)                                                                                      \
+  hipLaunchKernelGGL((gemv_kernel<MODE, UNR, NW>), grid, dim3(NW * 64), 0, stream, (const bf16_t*)A, (const bf16_t*)B, \
+                     C, bias, residual, M, N, K, lda, ldb, ldc, ldr, out_f32, alpha)
+  const bool small = (N + 15) / 16 < 512;
+  if (mode == 0) GV_LAUNCH(0, 8, 4);
+  else if (small && nw_small == 8) GV_LAUNCH(1, 8, 8);
+  else if (small && nw_small == 16) GV_LAUNCH(1, 4, 16);
+  else GV_LAUNCH(1, 8, 4);
+#undef GV_LAUNCH
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

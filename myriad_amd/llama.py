@@ -204,14 +204,14 @@ class LlamaHIP:
                 ops.rmsnorm_fwd(h, L["ln1"], self.eps, out=x_ext[:, :D])
                 self.lora.forward_border(li, x_ext, training=False)
                 qkv = ops.gemm(x_ext, L["wqkv_ext"])
-            ops.rope_(qkv, 0, 2 * H, hd, pos, self.cos, self.sin, 1.0)
             q3 = qkv.view(B, S, 3 * W)
             if pos_dev is None:
+                ops.rope_(qkv, 0, 2 * H, hd, pos, self.cos, self.sin, 1.0)
                 ops.copy3d_bf16(q3[:, :, W:], cache[:, past:past + S])       # append k|v (modeling_llama.py:190-195)
                 kc = cache[:, :past + S]
                 o, _ = ops.attn_fwd(q3[:, :, :W], kc[:, :, :W], kc[:, :, W:], H, hd, scale, causal=True, need_lse=False)
             else:
-                ops.kv_append(qkv[:, W:], cache, pos_dev)
+                ops.rope_kv_append(qkv, H, hd, pos, self.cos, self.sin, cache, pos_dev)   # rotary + append, one launch
                 o, _ = ops.attn_fwd(q3[:, :, :W], cache[:, :, :W], cache[:, :, W:], H, hd, scale, causal=False,
                                     kv_len=kvlen_dev, need_lse=False)
             h2 = ops.gemm(o.view(M, W), L["wo"], residual=h, out_dtype=F32)

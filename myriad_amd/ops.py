@@ -84,6 +84,18 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, b
     return out
 
 
+GEMM_KERNEL_NAMES = {0: "gemv_kernel", 1: "gemm_nt_kernel", 2: "gemm_256_kernel"}
+
+
+def gemm_plan(M: int, N: int, K: int, out_f32: bool = False, gelu: bool = False):
+    """(kernel id, K splits) the library will use for this shape -- mh_gemm_plan."""
+    import ctypes
+    kernel, splits = ctypes.c_int(0), ctypes.c_int(0)
+    flags = (1 if out_f32 else 0) | (2 if gelu else 0)
+    _lib.check(_L().mh_gemm_plan(M, N, K, flags, ctypes.addressof(kernel), ctypes.addressof(splits)), "mh_gemm_plan")
+    return kernel.value, splits.value
+
+
 def gemm_auto_f32(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     """f32 out = a @ b^T, choosing split-K when the output is small and the reduction long (wgrad shapes)."""
     M, K = a.shape
@@ -367,6 +379,18 @@ def kv_append(src2d: torch.Tensor, cache: torch.Tensor, pos_dev: torch.Tensor):
     B, cols = src2d.shape
     _lib.check(_L().mh_kv_append_bf16(_p(src2d), src2d.stride(0), _p(cache), cache.stride(0), cache.stride(1),
                                       _p(pos_dev), B, cols, _s()), "mh_kv_append_bf16")
+
+
+def rope_kv_append(qkv2d: torch.Tensor, n_heads: int, head_dim: int, pos: torch.Tensor, cos_tab: torch.Tensor,
+                   sin_tab: torch.Tensor, cache: torch.Tensor, pos_dev: torch.Tensor):
+    """Decode token: rotary on q (in place) and k, k|v written to cache[b, pos_dev[0]] -- one launch."""
+    _chk2d(qkv2d, BF16, "rope_kv_append.qkv")
+    B = qkv2d.shape[0]
+    if qkv2d.shape[1] < 3 * n_heads * head_dim or cache.shape[2] != 2 * n_heads * head_dim:
+        raise _lib.MyriadHipError("rope_kv_append: qkv must be [B, >=3W] and cache [B, T, 2W]")
+    _lib.check(_L().mh_rope_kv_append(_p(qkv2d), qkv2d.stride(0), n_heads, head_dim, _p(pos), _p(cos_tab), _p(sin_tab),
+                                      _p(cache), cache.stride(0), cache.stride(1), _p(pos_dev), B, _s()),
+               "mh_rope_kv_append")
 
 
 def add_i32_(x: torch.Tensor, delta: int):

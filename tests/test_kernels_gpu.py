@@ -155,6 +155,8 @@ CASES = [
     ("llama", 2, 32, 148, 148, 128, True, False, True),
     ("llama_short", 3, 4, 12, 12, 16, True, False, True),
     ("decode", 2, 32, 1, 150, 128, True, False, False),
+    ("decode_ragged", 3, 8, 1, 77, 128, False, False, True),     # KV cache with device-side valid lengths
+    ("decode_d64", 2, 12, 1, 33, 64, True, False, False),
 ]
 
 
@@ -245,6 +247,27 @@ def test_layernorm(M, D, eps):
 
 
 # ------------------------------------------------------------------------------------------------ elementwise
+def test_rope_kv_append_equals_rope_then_append():
+    """The fused decode-token kernel must be bit-identical to rope_ + kv_append (same fp32 arithmetic, one rounding)."""
+    B, H, D, T = 3, 4, 128, 20
+    W = H * D
+    qkv = bf(rnd(B, 3 * W, seed=71)).to(DEV)
+    cos, sin = R.rotary_tables(D, 64)
+    cs, sn = cos[:, :D // 2].contiguous().to(DEV), sin[:, :D // 2].contiguous().to(DEV)
+    pos = torch.full((B,), 7, dtype=torch.int32, device=DEV)
+    pos_dev = torch.tensor([7], dtype=torch.int32, device=DEV)
+    cache_a = bf(rnd(B, T, 2 * W, seed=72)).to(DEV)
+    cache_b = cache_a.clone()
+    a = qkv.clone()
+    ops.rope_(a, 0, 2 * H, D, pos, cs, sn, 1.0)
+    ops.kv_append(a[:, W:], cache_a, pos_dev)
+    b = qkv.clone()
+    ops.rope_kv_append(b, H, D, pos, cs, sn, cache_b, pos_dev)
+    assert torch.equal(a[:, :W], b[:, :W])                       # q rotated in place
+    assert torch.equal(cache_a, cache_b)                         # k (rotated) | v in row 7, every other row untouched
+    assert torch.equal(b[:, W:], qkv[:, W:])                     # the fused kernel leaves the k|v source alone
+
+
 def test_rope_fwd_bwd():
     B, S, H, D = 2, 40, 4, 128
     x = bf(rnd(B * S, 3 * H * D, seed=51)).to(DEV)

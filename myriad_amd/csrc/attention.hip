@@ -414,15 +414,17 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
 }
 
 // ------------------------------------------------------------------------------------------- C ABI
-// ---- Sq == 1 (KV-cache decode, modeling_llama.py:197-222 with past_key_value): one 4-wave workgroup per (b, h).
+// ---- Sq == 1 (KV-cache decode, modeling_llama.py:197-222 with past_key_value): one 16-wave workgroup per (b, h).
 // The MFMA tile kernel above spends ~19 us on this shape (one 64-row query tile with a single live row, K/V staged
-// through LDS tile by tile); here the work is what it is -- stream len x D of K, then len x D of V, once:
-//   scores: 16 lanes share a key (16 B of the row each), 4 keys per wave pass, 16 per workgroup pass -> LDS
+// through LDS tile by tile).  There are only B*H workgroups, so the kernel is a chain of load latencies: the work is
+// spread over 1024 threads to keep that chain short (a 4-wave version with one load per pass measured 16.5 us):
+//   scores: 16 lanes share a key (16 B of the row each), 64 keys per workgroup pass, two passes in flight -> LDS
 //   softmax: every wave reduces the LDS scores itself (len <= a few hundred)
-//   PV: lane owns two head dims, waves take keys round-robin, 8 independent 256-B row loads in flight per wave
+//   PV: lane owns two head dims, waves take keys round-robin, up to 8 independent 256-B row loads in flight per wave
 // fp32 throughout (the tile kernel rounds P to bf16 for its MFMA), output rounded to bf16 once.
-__global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
-  extern __shared__ float dsm[];                 // [Sk] scores, then [4][128] partial outputs
+#define DNW 16
+__global__ __launch_bounds__(DNW * 64) void attn_decode_kernel(AttnParams p) {
+  extern __shared__ float dsm[];                 // [Sk] scores, then [DNW][128] partial outputs
   const int b = blockIdx.x / p.H, h = blockIdx.x % p.H;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int len = p.kv_len ? p.kv_len[b] : p.Sk;
@@ -443,19 +445,26 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
 #pragma unroll
     for (int e = 0; e < 8; ++e) qf[e] = bf2f((bf16_t)qv[e]) * p.scale;
   }
-  for (int j0 = 0; j0 < len; j0 += 16) {
-    const int j = j0 + wave * 4 + kq;
-    float s = 0.f;
-    if (j < len && dim_ok) {
-      const short8_t kv = *reinterpret_cast<const short8_t*>(kp + (size_t)j * p.ldk + sub * 8);
+  for (int j0 = 0; j0 < len; j0 += 2 * DNW * 4) {
+    short8_t kv[2];
+    int jj[2];
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += qf[e] * bf2f((bf16_t)kv[e]);
+    for (int u = 0; u < 2; ++u) {
+      jj[u] = j0 + u * DNW * 4 + wave * 4 + kq;
+      kv[u] = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
+      if (jj[u] < len && dim_ok) kv[u] = *reinterpret_cast<const short8_t*>(kp + (size_t)jj[u] * p.ldk + sub * 8);
     }
-    s += __shfl_xor(s, 1, 64);
-    s += __shfl_xor(s, 2, 64);
-    s += __shfl_xor(s, 4, 64);
-    s += __shfl_xor(s, 8, 64);
-    if (sub == 0 && j < len) sc[j] = s;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      float s = 0.f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += qf[e] * bf2f((bf16_t)kv[u][e]);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      s += __shfl_xor(s, 4, 64);
+      s += __shfl_xor(s, 8, 64);
+      if (sub == 0 && jj[u] < len) sc[jj[u]] = s;
+    }
   }
   __syncthreads();
   // phase 2: softmax statistics (each wave for itself)
@@ -465,17 +474,17 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
   float sum = 0.f;
   for (int j = lane; j < len; j += 64) sum += __expf(sc[j] - mx);
   sum = wave_sum(sum);
-  // phase 3: o = sum_j p_j V[j]; lane owns dims 2*lane, 2*lane+1; wave w takes keys w, w+4, ...
+  // phase 3: o = sum_j p_j V[j]; lane owns dims 2*lane, 2*lane+1; wave w takes keys w, w+DNW, ...
   float o0 = 0.f, o1 = 0.f;
   const bool own = 2 * lane < D;
   int j = wave;
-  for (; j + 28 < len; j += 32) {
+  for (; j + 7 * DNW < len; j += 8 * DNW) {
     unsigned vv[8];
     float pj[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
-      vv[u] = own ? *reinterpret_cast<const unsigned*>(vp + (size_t)(j + 4 * u) * p.ldv + 2 * lane) : 0u;
-      pj[u] = __expf(sc[j + 4 * u] - mx);
+      vv[u] = own ? *reinterpret_cast<const unsigned*>(vp + (size_t)(j + DNW * u) * p.ldv + 2 * lane) : 0u;
+      pj[u] = __expf(sc[j + DNW * u] - mx);
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -483,11 +492,21 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
       o1 += pj[u] * bf2f((bf16_t)(vv[u] >> 16));
     }
   }
-  for (; j < len; j += 4) {
-    const unsigned vv = own ? *reinterpret_cast<const unsigned*>(vp + (size_t)j * p.ldv + 2 * lane) : 0u;
-    const float pj = __expf(sc[j] - mx);
-    o0 += pj * bf2f((bf16_t)(vv & 0xffffu));
-    o1 += pj * bf2f((bf16_t)(vv >> 16));
+  {                                              // remainder: up to 7 keys, loads issued together
+    unsigned vv[7];
+    float pj[7];
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      const int jr = j + DNW * u;
+      const bool ok = jr < len;
+      vv[u] = (own && ok) ? *reinterpret_cast<const unsigned*>(vp + (size_t)jr * p.ldv + 2 * lane) : 0u;
+      pj[u] = ok ? __expf(sc[jr] - mx) : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 7; ++u) {
+      o0 += pj[u] * bf2f((bf16_t)(vv[u] & 0xffffu));
+      o1 += pj[u] * bf2f((bf16_t)(vv[u] >> 16));
+    }
   }
   part[wave * 128 + 2 * lane] = o0;
   part[wave * 128 + 2 * lane + 1] = o1;
@@ -496,7 +515,7 @@ __global__ __launch_bounds__(256) void attn_decode_kernel(AttnParams p) {
     const float inv = len > 0 ? 1.f / sum : 0.f;
     float r0 = 0.f, r1 = 0.f;
 #pragma unroll
-    for (int w = 0; w < 4; ++w) {
+    for (int w = 0; w < DNW; ++w) {
       r0 += part[w * 128 + 2 * lane];
       r1 += part[w * 128 + 2 * lane + 1];
     }
@@ -558,8 +577,8 @@ extern "C" int mh_attn_fwd(const void* q, const void* k, const void* v, void* o,
   if (rc) return rc;
   if (ldo % 4) return MH_ERR_ARG;
   if (Sq == 1 && !bias && Sk <= 8192 && (ldv % 2) == 0) {   // KV-cache decode (causal or not: the one query sees every valid key)
-    const size_t sh = (((size_t)Sk + 63) & ~(size_t)63) * 4 + 4 * 128 * 4;
-    hipLaunchKernelGGL(attn_decode_kernel, dim3(B * H), dim3(256), sh, stream, p);
+    const size_t sh = (((size_t)Sk + 63) & ~(size_t)63) * 4 + DNW * 128 * 4;
+    hipLaunchKernelGGL(attn_decode_kernel, dim3(B * H), dim3(DNW * 64), sh, stream, p);
     MH_CHECK_LAUNCH();
     return MH_OK;
   }

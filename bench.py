@@ -75,6 +75,7 @@ class GemmProbe:
         self.ops = ops
         self.orig = ops.gemm
         self.records = []
+        self.bytes = {}
 
     def __enter__(self):
         ops = self.ops
@@ -86,6 +87,9 @@ class GemmProbe:
             e1.record()
             shp = (a.shape[0], b.shape[0], a.shape[1])
             self.records.append((e0, e1, 2.0 * shp[0] * shp[1] * shp[2], shp))
+            # algorithmic bytes of the launch: both bf16 operands once + the output once (+ the fp32 residual read)
+            self.bytes[shp] = self.bytes.get(shp, 0.0) + 2.0 * (shp[0] + shp[1]) * shp[2] + shp[0] * shp[1] * (
+                out.element_size() + (4 if kw.get("residual") is not None else 0))
             return out
 
         ops.gemm = timed
@@ -115,12 +119,14 @@ class GemmProbe:
         for shp, (cnt, ms, f) in shapes.items():
             kid, splits = self.ops.gemm_plan(*shp)
             key = (self.ops.GEMM_KERNEL_NAMES[kid], "split" if splits > 1 else "plain")
-            d = per.setdefault(key, [0, 0.0, 0.0])
+            d = per.setdefault(key, [0, 0.0, 0.0, 0.0])
             d[0] += cnt
             d[1] += ms
             d[2] += f
+            d[3] += self.bytes.get(shp, 0.0)
         self.per_kernel = {f"{k[0]}:{k[1]}": dict(launches=v[0], total_ms=round(v[1], 3), avg_us=round(1e3 * v[1] / v[0], 2),
-                                                   tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 1)) for k, v in per.items()}
+                                                   tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 1),
+                                                   algorithmic_mb_per_launch=round(v[3] / v[0] / 1e6, 1)) for k, v in per.items()}
         return dict(launches=n, total_ms=t_ms, avg_us=1e3 * t_ms / max(n, 1), tflops=fl / (t_ms * 1e-3) / 1e12 if t_ms else 0.0,
                     flops=fl)
 
@@ -270,8 +276,19 @@ def main():
         # dominant kernel = the plain-launch population with the most time (gemm_256_kernel on this workload)
         dom = max((k for k in pr.per_kernel if k.endswith(":plain")), key=lambda k: pr.per_kernel[k]["total_ms"])
         dk = pr.per_kernel[dom]
+        # HBM-side bytes per launch of the same kernel population come from separate rocprofv3 --pmc passes
+        # (tools/pmc_traffic.sh -> profiles/r01_gemm256_traffic.json); null if that file is not for this kernel
+        traffic = None
+        tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm256_traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if dom.split(":")[0] in tj.get("kernel", ""):
+                traffic = dict(bytes_per_launch=round(tj["traffic_bytes_per_launch"]), read=round(tj["read_bytes_per_launch"]),
+                               write=round(tj["write_bytes_per_launch"]),
+                               algorithmic_bytes_per_launch=round(dk["algorithmic_mb_per_launch"] * 1e6),
+                               source="profiles/r01_gemm256_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)")
         roof = dict(bound="mfma", kernel=dom.split(":")[0] + " (mh_gemm_bf16_nt, unsplit launches)", achieved=dk["tflops"],
-                    peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(dk["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=None,
+                    peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(dk["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=traffic,
                     launches_per_step=dk["launches"], avg_launch_us=dk["avg_us"], per_kernel=pr.per_kernel,
                     all_gemm=dict(launches=gs["launches"], avg_launch_us=round(gs["avg_us"], 2),
                                   tflops=round(gs["tflops"], 1), frac=round(gs["tflops"] / PEAK_BF16_TFLOPS, 4)),

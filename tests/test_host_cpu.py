@@ -123,3 +123,31 @@ def test_gradient_allreduce_world2_gloo():
     for r in range(2):
         assert torch.allclose(got[r][1], want, atol=1e-6)
     assert torch.equal(got[0][1], got[1][1])
+
+
+def test_gemm_policy_for_the_steps_shapes():
+    """mh_gemm_plan is host-only logic (no launch): which kernel / how many K splits the library picks.  Pins the
+    policy for the shapes of the fine-tune step (B*S = 1184 LLaMA rows, 2056 ViT rows) and the decode token."""
+    import ctypes
+
+    from myriad_amd import _lib, ops
+    lib = _lib.load()
+    try:
+        # the plan only looks at the workspace SIZE; the pointer is never dereferenced without a launch
+        lib.mh_set_workspace(ctypes.c_void_p(0x1000), 256 << 20)
+        plan = ops.gemm_plan
+        assert plan(1, 12288, 4096) == (0, 1) and plan(16, 32000, 4096) == (0, 1)        # decode rows: weight streaming
+        assert plan(1184, 12288, 4096) == (2, 1)                                         # qkv: 5 x 48 = 240 tiles of 256^2
+        assert plan(1184, 22016, 4096) == (2, 1)                                         # gate|up: 430 tiles, no split
+        assert plan(1184, 4096, 22016) == (2, 3)                                         # dgrad: 80 tiles -> 240 workgroups
+        assert plan(1184, 4096, 4096) == (2, 3)
+        assert plan(2056, 6144, 1408) == (2, 1)                                          # ViT fc1
+        k, s = plan(2056, 1408, 1408)                                                    # 54 tiles of 256^2: stays on 128^2
+        assert k == 1 and s >= 1
+        assert plan(256, 768, 768)[0] == 1 and plan(72, 4096, 25664)[0] == 1             # Q-Former / conv-stem sizes
+        lib.mh_set_workspace(None, 0)
+        assert plan(1184, 4096, 22016) == (1, 1)                                         # no workspace: nothing may split
+        kernel, splits = ctypes.c_int(), ctypes.c_int()
+        assert lib.mh_gemm_plan(0, 8, 64, 0, ctypes.addressof(kernel), ctypes.addressof(splits)) != 0   # bad dims rejected
+    finally:
+        lib.mh_set_workspace(None, 0)

@@ -210,6 +210,54 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(const bf16_t* __restri
       }
     }
     // the slice is private to the wave: program order + the compiler's lgkmcnt wait are the only ordering needed
+    if (!out_f32 && (ldc & 7) == 0) {
+      // bf16 output: 16-B stores, 8 lanes cover one 128-B row, 8 rows per pass (half the store instructions of the
+      // 8-B form; the store tail is issue-bound, not bandwidth-bound)
+      const int r8 = lane >> 3, c8 = lane & 7;
+      const int nc = n0 + wc * 64 + c8 * 8;
+#pragma unroll 4
+      for (int p = 0; p < 8; ++p) {
+        const int row = p * 8 + r8;
+        const int m = m0 + grp * 128 + h * 64 + row;
+        const float4_t va = *reinterpret_cast<const float4_t*>(ep + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
+        const float4_t vb = *reinterpret_cast<const float4_t*>(ep + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
+        if (m >= M || nc >= N) continue;
+        float v[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+        if (nc + 7 < N) {
+          if (bias) {
+            const float4_t b0 = *reinterpret_cast<const float4_t*>(bias + nc);
+            const float4_t b1 = *reinterpret_cast<const float4_t*>(bias + nc + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+          }
+          if (do_gelu) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+          }
+          if (res) {
+            const float4_t q0 = *reinterpret_cast<const float4_t*>(res + (size_t)m * ldr + nc);
+            const float4_t q1 = *reinterpret_cast<const float4_t*>(res + (size_t)m * ldr + nc + 4);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v[e] += q0[e]; v[4 + e] += q1[e]; }
+          }
+          uint4 pk;
+          pk.x = pack_bf2(v[0], v[1]);
+          pk.y = pack_bf2(v[2], v[3]);
+          pk.z = pack_bf2(v[4], v[5]);
+          pk.w = pack_bf2(v[6], v[7]);
+          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(Cv) + (size_t)m * ldc + nc) = pk;
+        } else {
+          for (int e = 0; e < 8 && nc + e < N; ++e) {
+            float x = v[e];
+            if (bias) x += bias[nc + e];
+            if (do_gelu) x = gelu_erf(x);
+            if (res) x += res[(size_t)m * ldr + nc + e];
+            reinterpret_cast<bf16_t*>(Cv)[(size_t)m * ldc + nc + e] = f2bf(x);
+          }
+        }
+      }
+      continue;
+    }
 #pragma unroll 4
     for (int p = 0; p < 16; ++p) {
       const int row = p * 4 + er;

@@ -75,6 +75,23 @@ __device__ __forceinline__ void stage_transposed(bf16_t* lds, const bf16_t* base
   }
 }
 
+// one global read of the tile, both LDS images (row-major for the S = X.Y^T operand, transposed for the X^T.dS one);
+// lanes run along rows so the 2-byte transposed stores are conflict-free, and the 16-byte row-major stores of 8
+// consecutive rows land on 8 different bank quads (row stride DP+8 elements)
+template <int DP>
+__device__ __forceinline__ void stage_both(bf16_t* lds_rm, bf16_t* lds_tr, const bf16_t* base, long ld, int r0, int nrows,
+                                           int D) {
+  constexpr int CH = DP / 8;
+  for (int idx = threadIdx.x; idx < 64 * CH; idx += 256) {
+    const int row = idx & 63, ch = idx >> 6;
+    short8_t v = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
+    if (r0 + row < nrows && ch * 8 < D) v = *reinterpret_cast<const short8_t*>(base + (long)(r0 + row) * ld + ch * 8);
+    *reinterpret_cast<short8_t*>(lds_rm + row * Lds<DP>::ROW + ch * 8) = v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) lds_tr[(ch * 8 + e) * Lds<DP>::TROW + row] = (bf16_t)v[e];
+  }
+}
+
 // A-operand fragment from a row-major tile: row = 16*j + (lane&15), k-chunk (kk*4 + lane>>4)
 template <int DP>
 __device__ __forceinline__ short8_t frag_rm(const bf16_t* lds, int j, int kk, int lr, int lg) {
@@ -260,9 +277,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
 
   for (int k0 = 0; k0 < kv_end; k0 += TK) {
     __syncthreads();
-    stage_rowmajor<DP>(Ks, kb, p.ldk, k0, kv_valid, p.D);
+    stage_both<DP>(Ks, Kt, kb, p.ldk, k0, kv_valid, p.D);
     stage_rowmajor<DP>(Vs, vb, p.ldv, k0, kv_valid, p.D);
-    stage_transposed<DP>(Kt, kb, p.ldk, k0, kv_valid, p.D);
     __syncthreads();
     float4_t s[4], dp[4];
 #pragma unroll
@@ -347,10 +363,8 @@ __global__ __launch_bounds__(256) void attn_bwd_dkv_kernel(AttnParams p) {
   const long sbase = ((long)b * p.H + h) * p.Sq;
   for (int q0 = q_start; q0 < p.Sq; q0 += TQ) {
     __syncthreads();
-    stage_rowmajor<DP>(Qs, qb, p.ldq, q0, p.Sq, p.D);
-    stage_rowmajor<DP>(Gs, gb, p.lddo, q0, p.Sq, p.D);
-    stage_transposed<DP>(Qt, qb, p.ldq, q0, p.Sq, p.D);
-    stage_transposed<DP>(Gt, gb, p.lddo, q0, p.Sq, p.D);
+    stage_both<DP>(Qs, Qt, qb, p.ldq, q0, p.Sq, p.D);
+    stage_both<DP>(Gs, Gt, gb, p.lddo, q0, p.Sq, p.D);
     if (threadIdx.x < 64) {
       const int qq = q0 + threadIdx.x;
       lse_s[threadIdx.x] = qq < p.Sq ? p.lse[sbase + qq] : 1e30f;

@@ -34,6 +34,23 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
   return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
 }
 
+// Counter-based dropout keep-mask (PEFT lora_dropout, reference myriad.py:171-178): a pure function of (seed, flat
+// element index), so backward regenerates it instead of storing it.  32-bit arithmetic only (murmur3 finaliser over a
+// seed/index mix): the first version used a 64-bit splitmix and its multi-word multiplies made the LoRA kernels
+// ALU-bound.  Returns 1/(1-p) for kept elements, 0 for dropped ones; u is a 24-bit uniform in [0,1).
+__device__ __forceinline__ float dropout_keep(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+  if (p <= 0.f) return 1.f;
+  unsigned h = (unsigned)idx * 0x9E3779B1u + ((unsigned)seed ^ ((unsigned)(idx >> 32) * 0x85EBCA77u));
+  h ^= (unsigned)(seed >> 32);
+  h ^= h >> 16;
+  h *= 0x85EBCA6Bu;
+  h ^= h >> 13;
+  h *= 0xC2B2AE35u;
+  h ^= h >> 16;
+  const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
+  return u >= p ? inv_keep : 0.f;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -458,14 +458,7 @@ extern "C" int mh_patchify_nchw(const float* img, void* out, int B, int C, int H
 
 // ---- counter-based dropout (PEFT lora_dropout, reference myriad.py:171-178): keep-mask = hash(seed, index) >= p ----
 // The mask is a pure function of (seed, flat element index), so backward regenerates it instead of storing it.
-__device__ __forceinline__ float keep_scale(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
-  unsigned long long z = seed + idx * 0x9E3779B97F4A7C15ull;
-  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
-  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
-  z ^= z >> 31;
-  const float u = (float)(z >> 40) * (1.0f / 16777216.0f);   // 24-bit uniform in [0,1)
-  return u >= p ? inv_keep : 0.f;
-}
+// (the keep-mask hash itself is dropout_keep in common.h, shared with lora.hip)
 // y[r][c] = x[r][c] * mask/(1-p), mask index = r*cols + c
 __global__ void dropout_bf16_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ y, long ldy, long rows,
                                     int cols8, float p, unsigned long long seed) {
@@ -478,7 +471,7 @@ __global__ void dropout_bf16_kernel(const bf16_t* __restrict__ x, long ldx, bf16
     short8_t o;
 #pragma unroll
     for (int e = 0; e < 8; ++e)
-      o[e] = (short)f2bf(bf2f((bf16_t)v[e]) * keep_scale(seed, (unsigned long long)(r * (long)cols8 * 8 + c + e), p, ik));
+      o[e] = (short)f2bf(bf2f((bf16_t)v[e]) * dropout_keep(seed, (unsigned long long)(r * (long)cols8 * 8 + c + e), p, ik));
     *reinterpret_cast<short8_t*>(y + r * ldy + c) = o;
   }
 }
@@ -493,7 +486,7 @@ __global__ void dropout_add_f32_kernel(const float* __restrict__ dy, long lddy, 
     const float4_t g = *reinterpret_cast<const float4_t*>(dy + r * lddy + c);
     float4_t a = *reinterpret_cast<const float4_t*>(acc + r * ldacc + c);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) a[e] += g[e] * keep_scale(seed, (unsigned long long)(r * (long)cols4 * 4 + c + e), p, ik);
+    for (int e = 0; e < 4; ++e) a[e] += g[e] * dropout_keep(seed, (unsigned long long)(r * (long)cols4 * 4 + c + e), p, ik);
     *reinterpret_cast<float4_t*>(acc + r * ldacc + c) = a;
   }
 }

@@ -167,3 +167,43 @@ def synthetic_batch(B: int, vocab: int, seed: int, n_before: int = 4, n_after: i
                 tgt[b, -k:] = 2
                 mask[b, -k:] = 0
     return image, maps, before, after, tgt, mask
+
+
+def expert_weights(D: int, blocks: int, C: int, n_taps: int, seed: int, n_tok: int = 257) -> Dict[str, torch.Tensor]:
+    """ImageBind vision-branch weights under the reference's state_dict names (imagebind_model.py) plus the anomaly
+    expert's per-tap decoder `image_decoder.fc.{i}` (adrefexpert_v2.py:16-29, 109)."""
+    g = torch.Generator().manual_seed(seed)
+    pre, trk, head = "modality_preprocessors.vision.", "modality_trunks.vision.", "modality_heads.vision."
+    sd = {pre + "cls_token": _gen((1, 1, D), g), pre + "rgbt_stem.proj.1.weight": _gen((D, 3, 2, 14, 14), g),
+          pre + "pos_embedding_helper.pos_embed": _gen((1, n_tok, D), g),
+          trk + "pre_transformer_layer.0.weight": _gen((D,), g, kind="ones"), trk + "pre_transformer_layer.0.bias": _gen((D,), g, kind="small")}
+    for i in range(blocks):
+        p = f"{trk}blocks.{i}."
+        sd[p + "attn.in_proj_weight"] = _gen((3 * D, D), g)
+        sd[p + "attn.in_proj_bias"] = _gen((3 * D,), g, kind="small")
+        sd[p + "attn.out_proj.weight"] = _gen((D, D), g)
+        sd[p + "attn.out_proj.bias"] = _gen((D,), g, kind="small")
+        sd[p + "norm_1.weight"] = _gen((D,), g, kind="ones")
+        sd[p + "norm_1.bias"] = _gen((D,), g, kind="small")
+        sd[p + "norm_2.weight"] = _gen((D,), g, kind="ones")
+        sd[p + "norm_2.bias"] = _gen((D,), g, kind="small")
+        sd[p + "mlp.fc1.weight"] = _gen((4 * D, D), g)
+        sd[p + "mlp.fc1.bias"] = _gen((4 * D,), g, kind="small")
+        sd[p + "mlp.fc2.weight"] = _gen((D, 4 * D), g)
+        sd[p + "mlp.fc2.bias"] = _gen((D,), g, kind="small")
+    sd[head + "0.weight"] = _gen((D,), g, kind="ones")
+    sd[head + "0.bias"] = _gen((D,), g, kind="small")
+    sd[head + "2.weight"] = _gen((C, D), g)
+    for i in range(n_taps):
+        sd[f"image_decoder.fc.{i}.weight"] = _gen((C, D), g, std=0.05)
+        sd[f"image_decoder.fc.{i}.bias"] = _gen((C,), g, kind="small")
+    return sd
+
+
+def expert_inputs(B: int, k: int, C: int, seed: int):
+    """(images [B,3,224,224], reference images [B*k,3,224,224], text features [B,2,C] L2-normalised)."""
+    g = torch.Generator().manual_seed(seed)
+    images = torch.randn(B, 3, 224, 224, generator=g)
+    refs = torch.randn(B * k, 3, 224, 224, generator=g)
+    text = torch.randn(B, 2, C, generator=g)
+    return images, refs, text / text.norm(dim=-1, keepdim=True)

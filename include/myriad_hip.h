@@ -166,6 +166,20 @@ int mh_scale_f32(float* x, float a, long n, mh_stream_t s);
 int mh_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, double lr, double beta1,
                   double beta2, double eps, double weight_decay, int step, double grad_scale, mh_stream_t s);
 
+/* K16 anomaly-map heads of the vision expert (adrefexpert_v2.py:243-301).  All f32.
+ * l2norm_rows: y = x / max(||x||, eps) (bf16 and/or f32 out) -- operands of the cosine similarities (:259, :283);
+ * pair_logits: out[row] = scale * [<p,t0>, <p,t1>] / ||p|| against the per-sample [normal, abnormal] text pair (:283-284);
+ * zs_accumulate: one tap of the zero-shot branch: mask_acc[B,h,h] += w*softmax(pair)[1], map_acc[B,S,S] += w*softmax(
+ *   bilinear(align_corners=True) upsampled pair)[1] (:285-296);
+ * rowmax_skip: acc[row] += w * max over columns c with c % period != 0 (best reference patch, class-token columns
+ *   skipped; :260-261);  bilinear_ac: align_corners=True resize, optionally 1 - x (:265-268). */
+int mh_l2norm_rows(const float* x, long ldx, void* y_bf16, float* y_f32, long ldy, int M, int D, float eps, mh_stream_t s);
+int mh_pair_logits(const float* p, long ldp, const float* text, float* out, long rows, int rows_per_batch, int C, float scale,
+                   mh_stream_t s);
+int mh_zs_accumulate(const float* logits, float* mask_acc, float* map_acc, int B, int h, int S, float w, mh_stream_t s);
+int mh_rowmax_skip(const float* scores, long lds, float* acc, long rows, int cols, int period, float w, mh_stream_t s);
+int mh_bilinear_ac(const float* in, float* out, int B, int h, int w, int H, int W, int one_minus, mh_stream_t s);
+
 /* library identity */
 const char* mh_version(void);
 int mh_target_arch(void); /* 950 */

@@ -462,3 +462,43 @@ def adamw_step(p, g, m, v, lr, wd, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_
     _lib.check(_L().mh_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), float(beta1),
                                   float(beta2), float(eps), float(wd), int(step), float(grad_scale), _s()),
                "mh_adamw_step")
+
+
+# --------------------------------------------------------------------------- vision-expert map heads (K16)
+def l2norm_rows(x: torch.Tensor, want_bf16: bool = True, want_f32: bool = False, eps: float = 1e-12):
+    """y = x / max(||x||, eps) row-wise; x [M, D] f32 (row stride free)."""
+    _chk2d(x, F32, "l2norm_rows.x")
+    M, D = x.shape
+    yb = torch.empty((M, D), dtype=BF16, device=x.device) if want_bf16 else None
+    yf = torch.empty((M, D), dtype=F32, device=x.device) if want_f32 else None
+    _lib.check(_L().mh_l2norm_rows(_p(x), x.stride(0), _p(yb), _p(yf), D, M, D, float(eps), _s()), "mh_l2norm_rows")
+    return yb, yf
+
+
+def pair_logits(p: torch.Tensor, text: torch.Tensor, rows_per_batch: int, scale: float = 100.0):
+    """p [rows, C] f32, text [B, 2, C] f32 -> [rows, 2] = scale * cos(p, text[row // rows_per_batch])."""
+    _chk2d(p, F32, "pair_logits.p")
+    rows, C = p.shape
+    out = torch.empty((rows, 2), dtype=F32, device=p.device)
+    _lib.check(_L().mh_pair_logits(_p(p), p.stride(0), _p(text.contiguous()), _p(out), rows, rows_per_batch, C, float(scale),
+                                   _s()), "mh_pair_logits")
+    return out
+
+
+def zs_accumulate(logits: torch.Tensor, mask_acc: torch.Tensor, map_acc: torch.Tensor, w: float):
+    B, h, S = mask_acc.shape[0], mask_acc.shape[-1], map_acc.shape[-1]
+    _lib.check(_L().mh_zs_accumulate(_p(logits), _p(mask_acc), _p(map_acc), B, h, S, float(w), _s()), "mh_zs_accumulate")
+
+
+def rowmax_skip(scores: torch.Tensor, acc: torch.Tensor, period: int, w: float):
+    """acc[row] += w * max over columns c with c % period != 0 (period 0: all columns)."""
+    rows, cols = scores.shape
+    _lib.check(_L().mh_rowmax_skip(_p(scores), scores.stride(0), _p(acc), rows, cols, period, float(w), _s()), "mh_rowmax_skip")
+
+
+def bilinear_ac(x: torch.Tensor, H: int, W: int, one_minus: bool = False):
+    """x [B, h, w] f32 -> [B, H, W], align_corners=True; optionally 1 - result."""
+    B, h, w = x.shape
+    out = torch.empty((B, H, W), dtype=F32, device=x.device)
+    _lib.check(_L().mh_bilinear_ac(_p(x.contiguous()), _p(out), B, h, w, H, W, int(one_minus), _s()), "mh_bilinear_ac")
+    return out

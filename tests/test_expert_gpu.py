@@ -1,0 +1,81 @@
+"""SURVEY 8 f-1 on the GPU: the HIP vision expert against the goldens the reference's own code produced and against the
+fp32 oracle on the same seeded weights.  bf16 GEMM operands, fp32 accumulation: tolerances stated per quantity."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from myriad_amd import ops  # noqa: E402
+from myriad_amd.vision_expert import VisionExpertHIP  # noqa: E402
+from oracle import expert_ref as X  # noqa: E402
+from tests import golden_utils as gu  # noqa: E402
+from tests.test_expert_oracle import load_case  # noqa: E402
+
+DEV = "cuda"
+
+
+def relerr(a, b):
+    a, b = a.double().cpu(), torch.as_tensor(b).double()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-30)).item()
+
+
+@pytest.mark.parametrize("name", ["d1280_3blk", "d1280_1blk_k2"])
+def test_vision_expert_vs_reference_golden(name):
+    g, cfg, sd, images, refs, text = load_case(name)
+    ex = VisionExpertHIP(sd, cfg["heads"], cfg["layers"], DEV)
+    emb, taps = ex.trunk.forward(images.to(DEV), want_embedding=True)
+    for i, t in enumerate(taps):
+        assert relerr(t[:, ::8, ::16], g[f"tap{i}_sub"]) < 2e-2, i            # activations: 2e-2 of max-abs
+    assert (emb.cpu() - torch.from_numpy(g["image_embeds"])).abs().max() < 2e-2   # unit vectors
+    zmap, zmask = ex.zero_shot(images, text)
+    # probabilities in [0,1]: logits are 100 * cosine, so a 2e-3 cosine error moves a mid-range probability by ~5e-2
+    assert (zmap.cpu() - torch.from_numpy(g["zs_map"])).abs().max() < 8e-2
+    assert (zmask.cpu() - torch.from_numpy(g["zs_mask"])).abs().max() < 8e-2
+    assert (zmap.cpu() - torch.from_numpy(g["zs_map"])).abs().mean() < 1e-2
+    omap, omask = ex.one_shot(images, refs)
+    assert (omap.cpu() - torch.from_numpy(g["os_map"])).abs().max() < 1e-2       # 1 - cosine similarity
+    assert (omask.cpu() - torch.from_numpy(g["os_mask"])).abs().max() < 1e-2
+    assert zmap.shape == (cfg["B"], 1, 224, 224) and omask.shape == (cfg["B"], 1, 16, 16)
+    # one trunk pass over [images ; references] must give the same four tensors (batch rows are independent)
+    (zmap2, zmask2), (omap2, omask2) = ex.forward(images, text, refs)
+    for a, b in ((zmap, zmap2), (zmask, zmask2), (omap, omap2), (omask, omask2)):
+        assert (a - b).abs().max() < 2e-3
+
+
+def test_map_head_kernels_vs_torch():
+    """The fp32 head kernels on their own against torch (tight tolerances: no bf16 involved)."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(37, 128, generator=g).to(DEV)
+    yb, yf = ops.l2norm_rows(x, want_f32=True)
+    ref = x / x.norm(dim=-1, keepdim=True)
+    assert relerr(yf, ref.cpu()) < 1e-6 and relerr(yb.float(), ref.cpu()) < 5e-3
+    B, L, C = 3, 256, 64
+    p = torch.randn(B * L, C, generator=g).to(DEV)
+    text = torch.randn(B, 2, C, generator=g)
+    text = (text / text.norm(dim=-1, keepdim=True)).to(DEV)
+    lg = ops.pair_logits(p, text, L, 100.0)
+    pn = (p / p.norm(dim=-1, keepdim=True)).view(B, L, C)
+    ref = 100.0 * pn @ text.transpose(-1, -2)
+    assert relerr(lg.view(B, L, 2), ref.cpu()) < 1e-5
+    mask = torch.zeros(B, 16, 16, device=DEV)
+    amap = torch.zeros(B, 224, 224, device=DEV)
+    ops.zs_accumulate(lg, mask, amap, 0.5)
+    ops.zs_accumulate(lg, mask, amap, 0.5)
+    grid = ref.permute(0, 2, 1).reshape(B, 2, 16, 16)
+    assert relerr(mask, torch.softmax(grid, 1)[:, 1].cpu()) < 1e-5
+    up = torch.nn.functional.interpolate(grid, size=224, mode="bilinear", align_corners=True)
+    assert relerr(amap, torch.softmax(up, 1)[:, 1].cpu()) < 1e-4
+    s = torch.randn(50, 514, generator=g).to(DEV)
+    acc = torch.ones(50, device=DEV)
+    ops.rowmax_skip(s, acc, 257, 0.25)
+    keep = torch.ones(514, dtype=torch.bool)
+    keep[0] = keep[257] = False
+    assert relerr(acc, (1 + 0.25 * s[:, keep.to(DEV)].max(dim=1).values).cpu()) < 1e-6
+    sim = torch.rand(2, 16, 16, generator=g).to(DEV)
+    up = ops.bilinear_ac(sim, 224, 224, one_minus=True)
+    ref = 1 - torch.nn.functional.interpolate(sim[:, None], size=224, mode="bilinear", align_corners=True)[:, 0]
+    assert relerr(up, ref.cpu()) < 1e-5
+    assert relerr(ops.bilinear_ac(sim, 16, 16), sim.cpu()) < 1e-7

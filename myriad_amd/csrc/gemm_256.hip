@@ -59,6 +59,14 @@ __device__ __forceinline__ int g2_off(int row, int chunk) { return row * 64 + ((
                                                        : (long long)__builtin_amdgcn_s_memtime();   \
   }
 
+// TRACE build: every workgroup's life cycle on the 100 MHz counter (entry, first tile landed, main loop done, stores
+// issued) at trace[1024 + 4*workgroup + slot] -- tools/gemm_life.py turns it into the fixed-cost breakdown
+#define G2_LIFE(slot)                                                                                    \
+  if (TRACE) {                                                                                           \
+    if (trace && blockIdx.y == 0 && threadIdx.x == 0)                                                    \
+      trace[1024 + 4 * blockIdx.x + (slot)] = (long long)__builtin_amdgcn_s_memrealtime();               \
+  }
+
 template <int N>
 __device__ __forceinline__ void g2_wait_vm() {
   if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -80,6 +88,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(const bf16_t* __restri
                                                           int flags, float alpha, int tiles_m, int kt_per_split,
                                                           long split_stride, long long* trace) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 stages][A 16K | B 16K]; reused by the epilogue
+  G2_LIFE(0)
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -142,6 +151,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(const bf16_t* __restri
     if (t < nt) issue(t);
   g2_wait_younger(nt - 1);
   __builtin_amdgcn_s_barrier();                       // tile 0 visible
+  G2_LIFE(1)
 
   // per-lane fragment byte offsets inside a stage (row & chunk permutation are tile-invariant)
   int offA[8], offB[4];
@@ -185,6 +195,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(const bf16_t* __restri
     G2_STAMP(5)
   }
   if (grp == 1 && nt > 0) mfma_block();
+  G2_LIFE(2)
 
   // ---- epilogue.  Every LDS-DMA has been retired and every fragment read is done (last barrier), so the ring is
   // free: each wave transposes its 128 x 64 fp32 tile through a private 16-KiB slice, 64 rows at a time, so that the
@@ -299,6 +310,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(const bf16_t* __restri
       }
     }
   }
+  G2_LIFE(3)
 }
 
 static long long* g2_trace = nullptr;

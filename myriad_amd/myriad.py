@@ -335,6 +335,24 @@ class MyriadHIP(nn.Module):
             image = torch.cat([image, samples["aug_image"]])          # myriad.py:315-316
         return image.to(self._dev, F32)
 
+    def attach_vision_expert(self, expert) -> None:
+        """Optional in-model producer of the anomaly maps (`self.vision_expert` of the reference, myriad.py:83-90):
+        a `myriad_amd.vision_expert.VisionExpertHIP`.  With it attached, samples may carry `expert_text_feats`
+        [B,2,C] (the cached per-class [normal, abnormal] text embeddings) and `ref_images` [B*k,3,224,224] instead of
+        ready-made maps; both map pairs then come from one trunk pass (myriad.py:331-345)."""
+        self.vision_expert = expert
+
+    def _maps_for(self, samples, key: str, image: torch.Tensor) -> torch.Tensor:
+        if key in samples:
+            return samples[key].to(self._dev, F32)
+        expert = getattr(self, "vision_expert", None)
+        if expert is None or "expert_text_feats" not in samples or "ref_images" not in samples:
+            raise KeyError(f"samples['{key}'] is required (or attach_vision_expert() + samples['expert_text_feats'] and "
+                           "samples['ref_images']): the vision expert is an upstream producer (SURVEY 2.1 row 10)")
+        (zs, _), (os_, _) = expert.forward(image, samples["expert_text_feats"], samples["ref_images"])
+        samples["anomaly_maps"], samples["oneshot_anomaly_maps"] = zs, os_      # both are computed once per batch
+        return samples[key]
+
     def _forward_impl(self, samples, need_grad: bool, vit_out=None):
         if self.use_lora:
             self.lora.step_seed = (self.lora.step_seed + 1) if need_grad else self.lora.step_seed
@@ -346,10 +364,7 @@ class MyriadHIP(nn.Module):
         if self.arch == "myriad":
             task = self.fixed_taskstage if self.fixed_taskstage is not None else random.choice([0, 1])  # :381
             key = "anomaly_maps" if task == 0 else "oneshot_anomaly_maps"
-            if key not in samples:
-                raise KeyError(f"samples['{key}'] is required: the vision expert is an upstream producer "
-                               "(SURVEY 2.1 row 10)")
-            maps = samples[key].to(self._dev, F32)
+            maps = self._maps_for(samples, key, image)
         before, after, tgt, tmask = self._tokenize(samples, image.shape[0], stage, True)
         parts = self.encode_img(image, maps, stage, need_grad, vit_out=vit_out)
         emb, attn, labels, img_slices = self._assemble(parts, before, after, tgt, tmask)
@@ -460,7 +475,7 @@ class MyriadHIP(nn.Module):
         maps = None
         if self.arch == "myriad":
             key = "oneshot_anomaly_maps" if self.k_shot > 0 else "anomaly_maps"
-            maps = samples[key].to(self._dev, F32)
+            maps = self._maps_for(samples, key, image)
         before, after, _, _ = self._tokenize(samples, image.shape[0], stage, False)
         parts = self.encode_img(image, maps, stage, False)
         emb, _, _, _ = self._assemble(parts, before, after, None, None)

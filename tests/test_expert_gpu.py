@@ -79,3 +79,28 @@ def test_map_head_kernels_vs_torch():
     ref = 1 - torch.nn.functional.interpolate(sim[:, None], size=224, mode="bilinear", align_corners=True)[:, 0]
     assert relerr(up, ref.cpu()) < 1e-5
     assert relerr(ops.bilinear_ac(sim, 16, 16), sim.cpu()) < 1e-7
+
+
+def test_model_with_attached_expert_equals_precomputed_maps():
+    """`attach_vision_expert`: maps produced inside the model from (image, text pair, references) give exactly the loss
+    of the same maps handed in through samples (myriad.py:331-345 vs the maps-as-inputs boundary)."""
+    from myriad_amd.myriad import MyriadHIP
+    from tests.test_model_gpu import _composite_sd
+    sd = _composite_sd([1, 2, 3, 4, 5])
+    image, _, before, after, tgt, tmask = gu.synthetic_batch(2, 1000, seed=6, pad_tail=1)
+    _, cfg, esd, _, _, _ = load_case("d1280_1blk_k2")
+    _, refs, text = gu.expert_inputs(2, 2, cfg["C"], seed=7)
+    expert = VisionExpertHIP(esd, cfg["heads"], cfg["layers"], DEV)
+    base = dict(image=image, before_ids=before, after_ids=after, target_ids=tgt, target_mask=tmask)
+    for task, key in ((0, "anomaly_maps"), (1, "oneshot_anomaly_maps")):
+        model = MyriadHIP(sd, dict(fixed_stage=1, fixed_taskstage=task, need_backward=False), device=DEV)
+        model.train()
+        with pytest.raises(KeyError):
+            model.forward(dict(base))                                  # no maps, no expert: loud failure
+        model.attach_vision_expert(expert)
+        s1 = dict(base, expert_text_feats=text, ref_images=refs)
+        l1 = float(model.forward(s1)["loss"].detach())
+        assert s1["anomaly_maps"].shape == (2, 1, 224, 224) and s1["oneshot_anomaly_maps"].shape == (2, 1, 224, 224)
+        (zs, _), (osm, _) = expert.forward(image.to(DEV), text, refs)
+        l2 = float(model.forward(dict(base, anomaly_maps=zs, oneshot_anomaly_maps=osm))["loss"].detach())
+        assert l1 == l2, (key, l1, l2)

@@ -183,3 +183,84 @@ class VisionExpertHIP:
         qt = [t[:B] for t in taps]
         rt = [t[B:] for t in taps]
         return self._zero_shot_from_taps(qt, text_feats), self._one_shot_from_taps(qt, rt)
+
+
+TPRE, TTRK, THEAD, TPOST = ("modality_preprocessors.text.", "modality_trunks.text.", "modality_heads.text.",
+                            "modality_postprocessors.text.")
+
+
+class ImageBindTextHIP:
+    """ImageBind text tower (multimodal_preprocessors.py:326-403, imagebind_model.py:330-337, 388-393, 423-425) and the
+    prompt ensemble of `encode_text_with_prompt_ensemble` (adrefexpert_v2.py:69-99).  Token ids are host inputs (the CLIP
+    BPE tokenisation is host-side string work).  The result depends only on the class name: compute once, cache, and
+    hand the [n_obj, 2, C] pair to `VisionExpertHIP.zero_shot`."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], n_heads: int, device, eps: float = 1e-6):
+        import math
+        dev = self.dev = torch.device(device)
+        self.H, self.eps = n_heads, eps
+
+        def bf(t):
+            return t.detach().to(device=dev, dtype=BF16).contiguous()
+
+        def f32(t):
+            return t.detach().to(device=dev, dtype=F32).contiguous()
+
+        self.tok = f32(sd[TPRE + "token_embedding.weight"])              # fp32 table: nn.Embedding is not autocast
+        self.pos = f32(sd[TPRE + "pos_embed"])                           # [1, 77, D]
+        self.ctx, self.D = self.pos.shape[1], self.pos.shape[2]
+        self.hd = self.D // n_heads
+        self.blocks: List[dict] = []
+        i = 0
+        while (TTRK + f"blocks.{i}.norm_1.weight") in sd:
+            p = TTRK + f"blocks.{i}."
+            self.blocks.append(dict(
+                n1w=f32(sd[p + "norm_1.weight"]), n1b=f32(sd[p + "norm_1.bias"]),
+                wqkv=bf(sd[p + "attn.in_proj_weight"]), bqkv=f32(sd[p + "attn.in_proj_bias"]),
+                wproj=bf(sd[p + "attn.out_proj.weight"]), bproj=f32(sd[p + "attn.out_proj.bias"]),
+                n2w=f32(sd[p + "norm_2.weight"]), n2b=f32(sd[p + "norm_2.bias"]),
+                w1=bf(sd[p + "mlp.fc1.weight"]), b1=f32(sd[p + "mlp.fc1.bias"]),
+                w2=bf(sd[p + "mlp.fc2.weight"]), b2=f32(sd[p + "mlp.fc2.bias"])))
+            i += 1
+        self.head_nw, self.head_nb = f32(sd[THEAD + "proj.0.weight"]), f32(sd[THEAD + "proj.0.bias"])
+        self.head_w = bf(sd[THEAD + "proj.1.weight"])
+        self.logit_scale = min(math.exp(float(sd[TPOST + "1.log_logit_scale"])), 100.0)
+
+    @torch.no_grad()
+    def forward(self, ids: torch.Tensor) -> torch.Tensor:
+        """ids [n, 77] int (host or device) -> [n, C] f32 = logit_scale * L2-normalised sentence embeddings."""
+        ids = ids.cpu().long()
+        n, L = ids.shape
+        D, H, hd = self.D, self.H, self.hd
+        M = n * L
+        h = ops.gather_rows_f32(self.tok, ids.reshape(-1).to(torch.int32).to(self.dev))
+        ops.copy3d(self.pos.expand(n, L, D), h.view(n, L, D), accumulate=True)
+        scale = hd ** -0.5
+        for blk in self.blocks:
+            xn, _ = ops.layernorm_fwd(h, blk["n1w"], blk["n1b"], self.eps)
+            qkv = ops.gemm(xn, blk["wqkv"], bias=blk["bqkv"]).view(n, L, 3 * D)
+            o, _ = ops.attn_fwd(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], H, hd, scale, causal=True, need_lse=False)
+            h = ops.gemm(o.view(M, D), blk["wproj"], bias=blk["bproj"], residual=h, out_dtype=F32)
+            xn, _ = ops.layernorm_fwd(h, blk["n2w"], blk["n2b"], self.eps)
+            a = ops.gemm(xn, blk["w1"], bias=blk["b1"], gelu=True)
+            h = ops.gemm(a, blk["w2"], bias=blk["b2"], residual=h, out_dtype=F32)
+        eot = (torch.arange(n) * L + ids.argmax(dim=-1)).to(torch.int32).to(self.dev)      # OpenCLIP pooling: the EOT row
+        e = ops.gather_rows_f32(h, eot)
+        en, _ = ops.layernorm_fwd(e, self.head_nw, self.head_nb, self.eps)
+        e = ops.gemm(en, self.head_w, out_dtype=F32)
+        _, e = ops.l2norm_rows(e, want_bf16=False, want_f32=True)
+        return ops.scale_(e, self.logit_scale)
+
+    @torch.no_grad()
+    def prompt_ensemble(self, ids_normal: torch.Tensor, ids_abnormal: torch.Tensor, n_obj: int) -> torch.Tensor:
+        """[n_obj * n_normal, 77] and [n_obj * n_abnormal, 77] prompt token ids -> [n_obj, 2, C]: per object the mean over
+        its sentences, L2-normalised (normalising the sum is the same vector)."""
+        en, ea = self.forward(ids_normal), self.forward(ids_abnormal)
+        C = en.shape[1]
+        out = torch.empty((n_obj * 2, C), dtype=F32, device=self.dev)
+        for src, col in ((en, 0), (ea, 1)):
+            per = src.shape[0] // n_obj
+            for i in range(n_obj):
+                out[i * 2 + col].copy_(ops.colsum(src[i * per:(i + 1) * per]))        # device-to-device row placement
+        _, feats = ops.l2norm_rows(out, want_bf16=False, want_f32=True)
+        return feats.view(n_obj, 2, C)

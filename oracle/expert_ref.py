@@ -115,3 +115,45 @@ def one_shot_maps(query_taps: List[torch.Tensor], ref_taps: List[torch.Tensor], 
     sim = sim.reshape(-1, 1, h, h)
     up = F.interpolate(sim, size=out_size, mode="bilinear", align_corners=True)
     return 1 - up, 1 - sim
+
+
+# ------------------------------------------------------------------------------------------------ text tower
+TPRE, TTRK, THEAD, TPOST = ("modality_preprocessors.text.", "modality_trunks.text.", "modality_heads.text.",
+                            "modality_postprocessors.text.")
+
+
+def text_trunk(sd: Dict[str, torch.Tensor], ids: torch.Tensor, heads: int, n_blocks: int) -> torch.Tensor:
+    """ImageBind text branch (multimodal_preprocessors.py:326-403; imagebind_model.py:330-337 trunk without the
+    pre-transformer LayerNorm, 388-393 head, 423-425 post-processor): token + position embedding, causal pre-LN blocks,
+    the row at the EOT token (= arg-max id, OpenCLIP pooling), LayerNorm -> Linear (no bias) -> L2 normalise ->
+    times min(exp(log_logit_scale), 100).  ids [n, 77] int64 -> [n, C]."""
+    g = lambda k: sd[k].float()
+    x = g(TPRE + "token_embedding.weight")[ids] + g(TPRE + "pos_embed")
+    n, L, D = x.shape
+    mask = torch.full((L, L), float("-inf")).triu_(1)
+    hd = D // heads
+    for i in range(n_blocks):
+        p = f"{TTRK}blocks.{i}."
+        h = F.layer_norm(x, (D,), g(p + "norm_1.weight"), g(p + "norm_1.bias"), 1e-6)
+        qkv = h @ g(p + "attn.in_proj_weight").t() + g(p + "attn.in_proj_bias")
+        q, k, v = (t.view(n, L, heads, hd).transpose(1, 2) for t in qkv.split(D, dim=-1))
+        a = ((q @ k.transpose(-1, -2)) / math.sqrt(hd) + mask).softmax(-1)
+        o = (a @ v).transpose(1, 2).reshape(n, L, D)
+        x = x + o @ g(p + "attn.out_proj.weight").t() + g(p + "attn.out_proj.bias")
+        h = F.layer_norm(x, (D,), g(p + "norm_2.weight"), g(p + "norm_2.bias"), 1e-6)
+        x = x + F.gelu(h @ g(p + "mlp.fc1.weight").t() + g(p + "mlp.fc1.bias")) @ g(p + "mlp.fc2.weight").t() + g(p + "mlp.fc2.bias")
+    eot = x[torch.arange(n), ids.argmax(dim=-1)]
+    e = F.layer_norm(eot, (D,), g(THEAD + "proj.0.weight"), g(THEAD + "proj.0.bias"), 1e-6) @ g(THEAD + "proj.1.weight").t()
+    e = F.normalize(e, dim=-1)
+    return torch.clip(g(TPOST + "1.log_logit_scale").exp(), max=100.0) * e
+
+
+def text_prompt_ensemble(emb_normal: torch.Tensor, emb_abnormal: torch.Tensor, n_obj: int) -> torch.Tensor:
+    """adrefexpert_v2.py:69-99: per object, mean over its normal / abnormal prompt sentences, L2 normalise each ->
+    [n_obj, 2, C] with row 0 normal, row 1 abnormal."""
+    C = emb_normal.shape[-1]
+    outs = []
+    for e in (emb_normal, emb_abnormal):
+        m = e.reshape(n_obj, -1, C).mean(dim=1, keepdim=True)
+        outs.append(m / m.norm(dim=-1, keepdim=True))
+    return torch.cat(outs, dim=1)

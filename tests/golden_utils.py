@@ -207,3 +207,46 @@ def expert_inputs(B: int, k: int, C: int, seed: int):
     refs = torch.randn(B * k, 3, 224, 224, generator=g)
     text = torch.randn(B, 2, C, generator=g)
     return images, refs, text / text.norm(dim=-1, keepdim=True)
+
+
+def expert_text_weights(D: int, blocks: int, C: int, seed: int, vocab: int = 49408, ctx: int = 77) -> Dict[str, torch.Tensor]:
+    """ImageBind text-branch weights under the reference's state_dict names (imagebind_model.py text modality)."""
+    g = torch.Generator().manual_seed(seed)
+    pre, trk, head = "modality_preprocessors.text.", "modality_trunks.text.", "modality_heads.text."
+    sd = {pre + "token_embedding.weight": _gen((vocab, D), g), pre + "pos_embed": _gen((1, ctx, D), g, std=0.01),
+          pre + "mask": torch.full((ctx, ctx), float("-inf")).triu_(1)}
+    for i in range(blocks):
+        p = f"{trk}blocks.{i}."
+        sd[p + "attn.in_proj_weight"] = _gen((3 * D, D), g, std=0.05)
+        sd[p + "attn.in_proj_bias"] = _gen((3 * D,), g, kind="small")
+        sd[p + "attn.out_proj.weight"] = _gen((D, D), g, std=0.05)
+        sd[p + "attn.out_proj.bias"] = _gen((D,), g, kind="small")
+        for n_ in ("norm_1", "norm_2"):
+            sd[p + n_ + ".weight"] = _gen((D,), g, kind="ones")
+            sd[p + n_ + ".bias"] = _gen((D,), g, kind="small")
+        sd[p + "mlp.fc1.weight"] = _gen((4 * D, D), g, std=0.05)
+        sd[p + "mlp.fc1.bias"] = _gen((4 * D,), g, kind="small")
+        sd[p + "mlp.fc2.weight"] = _gen((D, 4 * D), g, std=0.05)
+        sd[p + "mlp.fc2.bias"] = _gen((D,), g, kind="small")
+    sd[head + "proj.0.weight"] = _gen((D,), g, kind="ones")
+    sd[head + "proj.0.bias"] = _gen((D,), g, kind="small")
+    sd[head + "proj.1.weight"] = _gen((C, D), g, std=0.05)
+    sd["modality_postprocessors.text.1.log_logit_scale"] = torch.tensor(math.log(1 / 0.07))
+    return sd
+
+
+def expert_prompt_ids(n_obj: int, n_normal: int, n_abnormal: int, seed: int, vocab: int = 49408, ctx: int = 77):
+    """Token ids shaped like CLIP-tokenised prompt sentences: SOT, a few word ids, EOT (= the largest id), zero padding.
+    Returns (normal [n_obj*n_normal, ctx], abnormal [n_obj*n_abnormal, ctx]) int64."""
+    g = torch.Generator().manual_seed(seed)
+
+    def make(n):
+        ids = torch.zeros(n, ctx, dtype=torch.long)
+        for r in range(n):
+            ln = int(torch.randint(4, 14, (1,), generator=g))
+            ids[r, 0] = vocab - 2
+            ids[r, 1:1 + ln] = torch.randint(1, vocab - 2, (ln,), generator=g)
+            ids[r, 1 + ln] = vocab - 1
+        return ids
+
+    return make(n_obj * n_normal), make(n_obj * n_abnormal)

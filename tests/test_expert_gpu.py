@@ -104,3 +104,17 @@ def test_model_with_attached_expert_equals_precomputed_maps():
         (zs, _), (osm, _) = expert.forward(image.to(DEV), text, refs)
         l2 = float(model.forward(dict(base, anomaly_maps=zs, oneshot_anomaly_maps=osm))["loss"].detach())
         assert l1 == l2, (key, l1, l2)
+
+
+@pytest.mark.parametrize("name", ["d256_2blk", "d1024_1blk"])
+def test_text_tower_and_prompt_ensemble_vs_reference_golden(name):
+    from myriad_amd.vision_expert import ImageBindTextHIP
+    from tests.test_expert_oracle import load_text_case
+    g, cfg, sd, ids_n, ids_a = load_text_case(name)
+    tt = ImageBindTextHIP(sd, cfg["heads"], DEV)
+    en = tt.forward(ids_n)
+    # embeddings are unit vectors times 1/0.07 = 14.3: 2e-2 of max-abs like every activation comparison
+    assert relerr(en, g["emb_normal"]) < 2e-2
+    feats = tt.prompt_ensemble(ids_n, ids_a, cfg["n_obj"])
+    assert (feats.cpu() - torch.from_numpy(g["text_feats"])).abs().max() < 4e-3      # unit vectors, C = 1024
+    assert feats.shape == (cfg["n_obj"], 2, 1024)

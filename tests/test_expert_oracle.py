@@ -38,3 +38,23 @@ def test_expert_oracle_matches_reference(name):
     np.testing.assert_allclose(omap.numpy(), g["os_map"], atol=2e-5)
     np.testing.assert_allclose(omask.numpy(), g["os_mask"], atol=2e-5)
     assert zmap.shape == (cfg["B"], 1, 224, 224) and omask.shape == (cfg["B"], 1, 16, 16)
+
+
+def load_text_case(name):
+    g = np.load(os.path.join(GOLD, f"expert_text_{name}.npz"))
+    Dt, heads, blocks, C, n_obj, seed = (int(v) for v in g["cfg"])
+    sd = gu.expert_text_weights(Dt, blocks, C, seed)
+    ids_n, ids_a = gu.expert_prompt_ids(n_obj, 14, 10, seed + 1)
+    return g, dict(Dt=Dt, heads=heads, blocks=blocks, C=C, n_obj=n_obj), sd, ids_n, ids_a
+
+
+@pytest.mark.parametrize("name", ["d256_2blk", "d1024_1blk"])
+def test_text_tower_and_prompt_ensemble_match_reference(name):
+    torch.set_num_threads(8)
+    g, cfg, sd, ids_n, ids_a = load_text_case(name)
+    en = X.text_trunk(sd, ids_n, cfg["heads"], cfg["blocks"])
+    np.testing.assert_allclose(en.numpy(), g["emb_normal"], atol=3e-5, rtol=1e-5)         # scaled by 1/0.07 = 14.3
+    ea = X.text_trunk(sd, ids_a, cfg["heads"], cfg["blocks"])
+    feats = X.text_prompt_ensemble(en, ea, cfg["n_obj"])
+    np.testing.assert_allclose(feats.numpy(), g["text_feats"], atol=2e-6)
+    assert feats.shape == (cfg["n_obj"], 2, 1024)

@@ -125,6 +125,40 @@ def run_case(M, LinearLayer, forward, ns, name, D, heads, blocks, layers, C, B, 
     print("wrote", name, {k_: tuple(v.shape) for k_, v in out.items() if k_.startswith(("zs_", "os_", "tap", "image_"))})
 
 
+def run_text_case(M, ref, name, Dt, heads, blocks, C, n_obj, seed):
+    """Text tower + prompt ensemble through the reference's ImageBindModel text branch and its
+    encode_text_with_prompt_ensemble (AST-extracted; prompt_sentences holds seeded token ids, tokenisation is host-side)."""
+    sys.path.insert(0, ROOT)
+    from tests import golden_utils as gu
+    sd = gu.expert_text_weights(Dt, blocks, C, seed)
+    m = M.ImageBindModel(vision_embed_dim=32, vision_num_blocks=1, vision_num_heads=2, out_embed_dim=C, text_embed_dim=Dt,
+                         text_num_blocks=blocks, text_num_heads=heads, audio_embed_dim=32, audio_num_blocks=1, audio_num_heads=2,
+                         depth_embed_dim=32, depth_num_blocks=1, depth_num_heads=2, thermal_embed_dim=32, thermal_num_blocks=1,
+                         thermal_num_heads=2, imu_embed_dim=32, imu_num_blocks=1, imu_num_heads=2, audio_drop_path=0.0,
+                         imu_drop_path=0.0, layers=[0])
+    own = m.state_dict()
+    missing = [k for k in own if ".text." in k and k not in sd]
+    extra = [k for k in sd if k not in own]
+    assert not missing and not extra, (missing, extra)
+    m.load_state_dict(sd, strict=False)
+    m.eval()
+    n_normal, n_abnormal = 14, 10            # 7 / 5 states x 2 templates (adrefexpert_v2.py:34-38)
+    ids_n, ids_a = gu.expert_prompt_ids(n_obj, n_normal, n_abnormal, seed + 1)
+    src = open(os.path.join(ref, "minigpt4/models/adrefexpert_v2.py")).read()
+    fn = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name == "encode_text_with_prompt_ensemble"]
+    objs = [f"obj{i}" for i in range(n_obj)]
+    ns = {"torch": torch, "ModalityType": M.ModalityType,
+          "prompt_sentences": {o: [ids_n[i * n_normal:(i + 1) * n_normal], ids_a[i * n_abnormal:(i + 1) * n_abnormal]] for i, o in enumerate(objs)},
+          "prompt_templates": [0, 1], "prompt_normal": list(range(7)), "prompt_abnormal": list(range(5))}
+    exec(compile(ast.Module(body=fn, type_ignores=[]), "adrefexpert_v2.py(extract)", "exec"), ns)
+    with torch.no_grad():
+        emb_n = m({M.ModalityType.TEXT: ids_n})[M.ModalityType.TEXT][0]
+        feats = ns["encode_text_with_prompt_ensemble"](m, objs, "cpu")
+    np.savez_compressed(os.path.join(OUT, f"expert_text_{name}.npz"), cfg=np.array([Dt, heads, blocks, C, n_obj, seed]),
+                        emb_normal=emb_n.numpy(), text_feats=feats.numpy())
+    print("wrote text", name, tuple(emb_n.shape), tuple(feats.shape))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--ref", default="/root/reference")
@@ -137,3 +171,5 @@ if __name__ == "__main__":
     # weights and inputs come from tests/golden_utils.py (seeded), so the fixtures hold outputs only
     run_case(M, LinearLayer, forward, ns, "d1280_3blk", 1280, 16, 3, [0, 2], 64, B=2, k=1, seed=31)
     run_case(M, LinearLayer, forward, ns, "d1280_1blk_k2", 1280, 16, 1, [0], 128, B=2, k=2, seed=32)
+    run_text_case(M, a.ref, "d256_2blk", 256, 4, 2, 1024, n_obj=3, seed=41)          # reduced width/depth, head_dim 64 (C = 1024 is literal in the reference)
+    run_text_case(M, a.ref, "d1024_1blk", 1024, 16, 1, 1024, n_obj=1, seed=42)       # full width, one block

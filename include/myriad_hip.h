@@ -40,6 +40,14 @@ int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int
  * 2 = 256x256x32 tile (gemm_256_kernel).  For profilers and benchmarks that attribute time per kernel. */
 int mh_gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits);
 
+/* Linear + residual add + the RMSNorm that consumes the sum (modeling_llama.py:281-293 then :66-74 of the next block):
+ * H[M,N] = A.B^T + residual (f32, the new residual stream), Y[M,N] = bf16(norm_w * H * rsqrt(mean(H^2) + eps)).
+ * When the GEMM is split along K the slab reduction, the residual add and the norm run as ONE kernel; otherwise this is
+ * mh_gemm_bf16_nt followed by mh_rmsnorm_fwd.  Both forms give bit-identical H and Y. */
+int mh_gemm_residual_rmsnorm(const void* A, int lda, const void* B, int ldb, float* H, int ldh, const float* residual,
+                             int ldr, const float* norm_w, float eps, void* Y, long ldy, int M, int N, int K,
+                             mh_stream_t s);
+
 /* Scratch for the automatic split-K path of mh_gemm_bf16_nt (used for shapes whose tile count under-fills the
  * 256 CUs).  The caller owns the buffer; pass NULL to disable.  Not needed for correctness. */
 int mh_set_workspace(void* ptr, long bytes);

@@ -348,7 +348,48 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, void* __restr
   }
 }
 
-static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t stream) {
+// split-K reduce fused with the RMSNorm that consumes the result (o_proj -> post-attention norm, down_proj -> next
+// layer's input norm; modeling_llama.py:66-74, 281-293): one workgroup per row sums the slabs in the fixed order, adds the
+// fp32 residual, writes the new residual stream AND its normalised bf16 copy.  Same expressions, same summation order
+// and the same 256-thread block reduction as splitk_reduce_kernel followed by rmsnorm_fwd_kernel, so the pair of outputs
+// is bit-identical to the two-launch form it replaces (one launch and one read of the fp32 stream less per use).
+__global__ __launch_bounds__(256) void splitk_reduce_rmsnorm_kernel(const float* __restrict__ ws, const float* res, float* hout,
+                                                                    const float* __restrict__ w, bf16_t* __restrict__ y,
+                                                                    int N, long ldr, long ldh, long ldy, long slab,
+                                                                    int splits, float eps) {
+  __shared__ float red[4];
+  const long row = blockIdx.x;
+  float4_t hv[8];                                   // N <= 8192
+  float ss = 0.f;
+  int c = 0;
+  for (int i = threadIdx.x * 4; i < N; i += 1024, ++c) {
+    float4_t sacc = *reinterpret_cast<const float4_t*>(ws + row * N + i);
+    for (int k = 1; k < splits; ++k) {
+      const float4_t p = *reinterpret_cast<const float4_t*>(ws + (long)k * slab + row * N + i);
+      sacc[0] += p[0]; sacc[1] += p[1]; sacc[2] += p[2]; sacc[3] += p[3];
+    }
+    float v[4] = {sacc[0] * 1.0f, sacc[1] * 1.0f, sacc[2] * 1.0f, sacc[3] * 1.0f};
+    if (res) {
+      const float4_t r4 = *reinterpret_cast<const float4_t*>(res + row * ldr + i);
+      v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
+    }
+    hv[c] = (float4_t){v[0], v[1], v[2], v[3]};
+    *reinterpret_cast<float4_t*>(hout + row * ldh + i) = hv[c];
+    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+  }
+  ss = block_sum<4>(ss, red);
+  const float r = rsqrtf(ss / N + eps);
+  c = 0;
+  for (int i = threadIdx.x * 4; i < N; i += 1024, ++c) {
+    const float4_t g = *reinterpret_cast<const float4_t*>(w + i);
+    uint2 pk;
+    pk.x = pack_bf2(g[0] * (hv[c][0] * r), g[1] * (hv[c][1] * r));
+    pk.y = pack_bf2(g[2] * (hv[c][2] * r), g[3] * (hv[c][3] * r));
+    *reinterpret_cast<uint2*>(y + row * ldy + i) = pk;
+  }
+}
+
+static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t stream, bool reduce = true) {
   const int nt = g0.K / 64;
   if (splits > nt) splits = nt;
   const int tps = (nt + splits - 1) / splits;
@@ -366,6 +407,7 @@ static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t str
   else
     rc = launch_gemm<0, 2, 128, 2>(g, stream);
   if (rc) return rc;
+  if (!reduce) return MH_OK;                        // the caller consumes the slabs itself
   long gsz = ((long)g0.M * g0.N / 4 + 255) / 256;
   if (gsz > 4096) gsz = 4096;
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)gsz), dim3(256), 0, stream, ws, g0.C, g0.bias, g0.residual, g0.M,
@@ -468,6 +510,37 @@ extern "C" int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
     if (best > 1 && (size_t)best * M * N * sizeof(float) <= g_ws_bytes) return run_splitk(g, best, g_ws, stream);
   }
   return dispatch(g, stream);
+}
+
+extern "C" int mh_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, long ldy, int M, int D, float eps, hipStream_t stream);
+
+// H[M,N] = A.B^T + residual (fp32), Y = RMSNorm(H) * w (bf16): the Linear + residual add + next RMSNorm of a LLaMA layer
+extern "C" int mh_gemm_residual_rmsnorm(const void* A, int lda, const void* B, int ldb, float* H, int ldh,
+                                        const float* residual, int ldr, const float* norm_w, float eps, void* Y, long ldy,
+                                        int M, int N, int K, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return MH_OK;
+  if (!norm_w || !H || !Y || (N % 4) != 0 || (ldy % 4) != 0) return MH_ERR_ARG;
+  int kernel = 1, splits = 1;
+  if (K > 0) gemm_plan(M, N, K, MH_GEMM_OUT_F32, &kernel, &splits);
+  if (splits > 1 && kernel != 0 && N <= 8192 && (ldh % 4) == 0 && (!residual || (ldr % 4) == 0) && (K % 64) == 0 &&
+      (lda % 8) == 0 && (ldb % 8) == 0 && !(((uintptr_t)A | (uintptr_t)B | (uintptr_t)H) & 15)) {
+    GemmArgs g = {A, lda, B, ldb, (void*)H, ldh, M, N, K, nullptr, residual, ldr, MH_GEMM_OUT_F32, 1.0f, 1, K / 64, 0L};
+    if (kernel == 2) g.flags |= 12 << MH_GEMM_VARIANT_SHIFT;
+    const int nt = K / 64;                          // the split count run_splitk will settle on
+    int sp = splits > nt ? nt : splits;
+    const int tps = (nt + sp - 1) / sp;
+    sp = (nt + tps - 1) / tps;
+    int rc = run_splitk(g, splits, g_ws, stream, /*reduce=*/false);
+    if (rc) return rc;
+    hipLaunchKernelGGL(splitk_reduce_rmsnorm_kernel, dim3(M), dim3(256), 0, stream, g_ws, residual, H, norm_w, (bf16_t*)Y, N,
+                       (long)ldr, (long)ldh, ldy, (long)M * N, sp, eps);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+  }
+  int rc = mh_gemm_bf16_nt(A, lda, B, ldb, H, ldh, M, N, K, nullptr, residual, ldr, MH_GEMM_OUT_F32, 1.0f, stream);
+  if (rc) return rc;
+  if (ldh != N) return MH_ERR_ARG;                  // rmsnorm_fwd reads a dense [M, N] stream
+  return mh_rmsnorm_fwd(H, norm_w, Y, ldy, M, N, eps, stream);
 }
 
 // ---- explicit split-K entry (wgrad of the conv stem: M,N small, K huge); caller passes the scratch ----

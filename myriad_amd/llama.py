@@ -106,14 +106,21 @@ class LlamaHIP:
         lora = self.lora
         if lora is not None:
             lora.refresh(self.layers)
+        # The RMSNorm that consumes a residual-stream GEMM rides that GEMM's split-K reduce (ops.gemm_residual_rmsnorm):
+        # o_proj -> post-attention norm, down_proj -> the NEXT layer's input norm (written straight into that layer's
+        # bordered LoRA operand when LoRA is on).  Only layer 0's input norm is a launch of its own.
+        def norm_target(li):
+            if lora is None:
+                return None
+            return lora.x_ext(li, M)[:, :D]
+
+        xn = ops.rmsnorm_fwd(h, self.layers[0]["ln1"], self.eps, out=norm_target(0)) if self.layers else None
         for li, L in enumerate(self.layers):
             lsave = None
             if lora is None:
-                xn = ops.rmsnorm_fwd(h, L["ln1"], self.eps)
                 qkv = ops.gemm(xn, L["wqkv"])                               # [M, 3W] bf16
             else:   # q/v LoRA rides the qkv GEMM as a 64-column K border (myriad_amd/lora.py)
-                x_ext = lora.x_ext(li, M)
-                ops.rmsnorm_fwd(h, L["ln1"], self.eps, out=x_ext[:, :D])
+                x_ext = lora.x_ext(li, M)                                   # [:, :D] already holds rmsnorm(h)
                 p_eff, seed = lora.forward_border(li, x_ext)
                 qkv = ops.gemm(x_ext, L["wqkv_ext"])
                 lsave = (x_ext, p_eff, seed)
@@ -121,11 +128,14 @@ class LlamaHIP:
             q3 = qkv.view(B, S, 3 * W)
             o, lse = ops.attn_fwd(q3[:, :, :W], q3[:, :, W:2 * W], q3[:, :, 2 * W:], H, hd, scale, causal=True,
                                   kv_len=kv_len)
-            h2 = ops.gemm(o.view(M, W), L["wo"], residual=h, out_dtype=F32)
-            xn2 = ops.rmsnorm_fwd(h2, L["ln2"], self.eps)
+            h2, xn2 = ops.gemm_residual_rmsnorm(o.view(M, W), L["wo"], h, L["ln2"], self.eps)
             gu = ops.gemm(xn2, L["wgu"])                                    # [M, 2I]
             act = ops.silu_mul_fwd(gu)
-            h3 = ops.gemm(act, L["wd"], residual=h2, out_dtype=F32)
+            if li + 1 < len(self.layers):
+                h3, xn = ops.gemm_residual_rmsnorm(act, L["wd"], h2, self.layers[li + 1]["ln1"], self.eps,
+                                                   y_out=norm_target(li + 1))
+            else:
+                h3 = ops.gemm(act, L["wd"], residual=h2, out_dtype=F32)     # the final norm runs on label rows only
             if save_for_backward:
                 saved.append((h, qkv, o, lse, h2, gu, lsave))
             h = h3

@@ -502,3 +502,21 @@ def bilinear_ac(x: torch.Tensor, H: int, W: int, one_minus: bool = False):
     out = torch.empty((B, H, W), dtype=F32, device=x.device)
     _lib.check(_L().mh_bilinear_ac(_p(x.contiguous()), _p(out), B, h, w, H, W, int(one_minus), _s()), "mh_bilinear_ac")
     return out
+
+
+def gemm_residual_rmsnorm(a: torch.Tensor, b: torch.Tensor, residual: torch.Tensor, norm_w: torch.Tensor, eps: float,
+                          y_out: Optional[torch.Tensor] = None):
+    """(h, y): h = a @ b^T + residual (f32), y = rmsnorm(h) * norm_w (bf16; y_out may be a [M, N] view of a wider buffer).
+    One launch less than gemm + rmsnorm_fwd when the GEMM is split along K; bit-identical results either way."""
+    _chk2d(a, BF16, "gemm_residual_rmsnorm.a")
+    _chk2d(b, BF16, "gemm_residual_rmsnorm.b")
+    _chk2d(residual, F32, "gemm_residual_rmsnorm.residual")
+    M, K = a.shape
+    N = b.shape[0]
+    h = torch.empty((M, N), dtype=F32, device=a.device)
+    y = y_out if y_out is not None else torch.empty((M, N), dtype=BF16, device=a.device)
+    _chk2d(y, BF16, "gemm_residual_rmsnorm.y")
+    rc = _L().mh_gemm_residual_rmsnorm(_p(a), a.stride(0), _p(b), b.stride(0), _p(h), N, _p(residual), residual.stride(0),
+                                       _p(norm_w), float(eps), _p(y), y.stride(0), M, N, K, _s())
+    _lib.check(rc, f"mh_gemm_residual_rmsnorm M={M} N={N} K={K}")
+    return h, y

@@ -118,6 +118,24 @@ def test_skinny_m_weight_streaming_gemm(M, N, K):
     assert relerr(ops.gemm(a, b, out_dtype=torch.float32), ops.gemm(a, b, out_dtype=torch.float32, variant=1)) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(1184, 4096, 4096), (1184, 4096, 11008), (300, 512, 256), (2056, 1408, 6144)])
+def test_gemm_residual_rmsnorm_is_bit_identical_to_two_launches(M, N, K):
+    """Split-K reduce + residual add + RMSNorm in one kernel (split shapes) or GEMM then norm (the rest): same bits."""
+    ops.ensure_workspace(DEV)
+    a = bf(rnd(M, K, seed=31)).to(DEV)
+    b = bf(rnd(N, K, seed=32) * 0.05).to(DEV)
+    res = rnd(M, N, seed=33).to(DEV)
+    w = (1 + 0.1 * rnd(N, seed=34)).to(DEV)
+    h_ref = ops.gemm(a, b, residual=res, out_dtype=torch.float32)
+    y_ref = ops.rmsnorm_fwd(h_ref, w, 1e-6)
+    h, y = ops.gemm_residual_rmsnorm(a, b, res, w, 1e-6)
+    assert torch.equal(h, h_ref) and torch.equal(y, y_ref)
+    wide = torch.zeros(M, N + 64, dtype=torch.bfloat16, device=DEV)       # the bordered LoRA operand: strided y
+    h2, y2 = ops.gemm_residual_rmsnorm(a, b, res, w, 1e-6, y_out=wide[:, :N])
+    assert torch.equal(h2, h_ref) and torch.equal(wide[:, :N], y_ref) and wide[:, N:].abs().max() == 0
+    assert relerr(h, a.float() @ b.float().T + res) < 1e-4
+
+
 def test_gemm_rejects_bad_k():
     a = bf(rnd(8, 40)).to(DEV)
     b = bf(rnd(8, 40)).to(DEV)

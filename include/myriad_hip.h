@@ -48,6 +48,12 @@ int mh_gemm_residual_rmsnorm(const void* A, int lda, const void* B, int ldb, flo
                              int ldr, const float* norm_w, float eps, void* Y, long ldy, int M, int N, int K,
                              mh_stream_t s);
 
+/* Same for the pre-LN ViT blocks (eva_vit.py:173-180; ImageBind transformer.py:160-163): H = A.B^T + bias + residual,
+ * Y = bf16(LayerNorm(H) * norm_w + norm_b), dense [M,N] outputs. */
+int mh_gemm_residual_layernorm(const void* A, int lda, const void* B, int ldb, float* H, int ldh, const float* bias,
+                               const float* residual, int ldr, const float* norm_w, const float* norm_b, float eps, void* Y,
+                               int M, int N, int K, mh_stream_t s);
+
 /* Scratch for the automatic split-K path of mh_gemm_bf16_nt (used for shapes whose tile count under-fills the
  * 256 CUs).  The caller owns the buffer; pass NULL to disable.  Not needed for correctness. */
 int mh_set_workspace(void* ptr, long bytes);

@@ -353,14 +353,18 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, void* __restr
 // fp32 residual, writes the new residual stream AND its normalised bf16 copy.  Same expressions, same summation order
 // and the same 256-thread block reduction as splitk_reduce_kernel followed by rmsnorm_fwd_kernel, so the pair of outputs
 // is bit-identical to the two-launch form it replaces (one launch and one read of the fp32 stream less per use).
-__global__ __launch_bounds__(256) void splitk_reduce_rmsnorm_kernel(const float* __restrict__ ws, const float* res, float* hout,
-                                                                    const float* __restrict__ w, bf16_t* __restrict__ y,
-                                                                    int N, long ldr, long ldh, long ldy, long slab,
-                                                                    int splits, float eps) {
+// NORM 0: RMSNorm (y = w * h * rsqrt(mean(h^2) + eps));  NORM 1: LayerNorm (y = (h - mean) * rsqrt(var + eps) * w + nb,
+// eva_vit.py:175-179 / ImageBind transformer.py:160-163) -- each written exactly as norm.hip writes it.
+template <int NORM>
+__global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+                                                                 const float* res, float* hout, const float* __restrict__ w,
+                                                                 const float* __restrict__ nb, bf16_t* __restrict__ y, int N,
+                                                                 long ldr, long ldh, long ldy, long slab, int splits,
+                                                                 float eps) {
   __shared__ float red[4];
   const long row = blockIdx.x;
   float4_t hv[8];                                   // N <= 8192
-  float ss = 0.f;
+  float acc1 = 0.f;                                 // sum of squares (RMS) or plain sum (LayerNorm)
   int c = 0;
   for (int i = threadIdx.x * 4; i < N; i += 1024, ++c) {
     float4_t sacc = *reinterpret_cast<const float4_t*>(ws + row * N + i);
@@ -369,22 +373,47 @@ __global__ __launch_bounds__(256) void splitk_reduce_rmsnorm_kernel(const float*
       sacc[0] += p[0]; sacc[1] += p[1]; sacc[2] += p[2]; sacc[3] += p[3];
     }
     float v[4] = {sacc[0] * 1.0f, sacc[1] * 1.0f, sacc[2] * 1.0f, sacc[3] * 1.0f};
+    if (bias) {
+      const float4_t b4 = *reinterpret_cast<const float4_t*>(bias + i);
+      v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+    }
     if (res) {
       const float4_t r4 = *reinterpret_cast<const float4_t*>(res + row * ldr + i);
       v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
     }
     hv[c] = (float4_t){v[0], v[1], v[2], v[3]};
     *reinterpret_cast<float4_t*>(hout + row * ldh + i) = hv[c];
-    ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    if (NORM == 0) acc1 += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    else acc1 += v[0] + v[1] + v[2] + v[3];
   }
-  ss = block_sum<4>(ss, red);
-  const float r = rsqrtf(ss / N + eps);
+  float mean = 0.f, r;
+  if (NORM == 0) {
+    r = rsqrtf(block_sum<4>(acc1, red) / N + eps);
+  } else {
+    mean = block_sum<4>(acc1, red) / N;
+    float ss = 0.f;
+    c = 0;
+    for (int i = threadIdx.x * 4; i < N; i += 1024, ++c) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ss += (hv[c][e] - mean) * (hv[c][e] - mean);
+    }
+    r = rsqrtf(block_sum<4>(ss, red) / N + eps);
+  }
   c = 0;
   for (int i = threadIdx.x * 4; i < N; i += 1024, ++c) {
     const float4_t g = *reinterpret_cast<const float4_t*>(w + i);
+    float o[4];
+    if (NORM == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = g[e] * (hv[c][e] * r);
+    } else {
+      const float4_t bb = *reinterpret_cast<const float4_t*>(nb + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (hv[c][e] - mean) * r * g[e] + bb[e];
+    }
     uint2 pk;
-    pk.x = pack_bf2(g[0] * (hv[c][0] * r), g[1] * (hv[c][1] * r));
-    pk.y = pack_bf2(g[2] * (hv[c][2] * r), g[3] * (hv[c][3] * r));
+    pk.x = pack_bf2(o[0], o[1]);
+    pk.y = pack_bf2(o[2], o[3]);
     *reinterpret_cast<uint2*>(y + row * ldy + i) = pk;
   }
 }
@@ -513,13 +542,15 @@ extern "C" int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
 }
 
 extern "C" int mh_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, long ldy, int M, int D, float eps, hipStream_t stream);
+extern "C" int mh_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, int M, int D,
+                                float eps, hipStream_t stream);
 
-// H[M,N] = A.B^T + residual (fp32), Y = RMSNorm(H) * w (bf16): the Linear + residual add + next RMSNorm of a LLaMA layer
-extern "C" int mh_gemm_residual_rmsnorm(const void* A, int lda, const void* B, int ldb, float* H, int ldh,
-                                        const float* residual, int ldr, const float* norm_w, float eps, void* Y, long ldy,
-                                        int M, int N, int K, hipStream_t stream) {
+// H[M,N] = A.B^T (+bias) + residual (fp32), Y = norm(H) (bf16): a Linear, its residual add and the norm that reads the sum
+static int gemm_residual_norm(int norm, const void* A, int lda, const void* B, int ldb, float* H, int ldh, const float* bias,
+                              const float* residual, int ldr, const float* norm_w, const float* norm_b, float eps, void* Y,
+                              long ldy, int M, int N, int K, hipStream_t stream) {
   if (M <= 0 || N <= 0) return MH_OK;
-  if (!norm_w || !H || !Y || (N % 4) != 0 || (ldy % 4) != 0) return MH_ERR_ARG;
+  if (!norm_w || !H || !Y || (N % 4) != 0 || (ldy % 4) != 0 || (norm == 1 && (!norm_b || ldy != N))) return MH_ERR_ARG;
   int kernel = 1, splits = 1;
   if (K > 0) gemm_plan(M, N, K, MH_GEMM_OUT_F32, &kernel, &splits);
   if (splits > 1 && kernel != 0 && N <= 8192 && (ldh % 4) == 0 && (!residual || (ldr % 4) == 0) && (K % 64) == 0 &&
@@ -532,15 +563,32 @@ extern "C" int mh_gemm_residual_rmsnorm(const void* A, int lda, const void* B, i
     sp = (nt + tps - 1) / tps;
     int rc = run_splitk(g, splits, g_ws, stream, /*reduce=*/false);
     if (rc) return rc;
-    hipLaunchKernelGGL(splitk_reduce_rmsnorm_kernel, dim3(M), dim3(256), 0, stream, g_ws, residual, H, norm_w, (bf16_t*)Y, N,
-                       (long)ldr, (long)ldh, ldy, (long)M * N, sp, eps);
+    if (norm == 0)
+      hipLaunchKernelGGL(splitk_reduce_norm_kernel<0>, dim3(M), dim3(256), 0, stream, g_ws, bias, residual, H, norm_w, norm_b,
+                         (bf16_t*)Y, N, (long)ldr, (long)ldh, ldy, (long)M * N, sp, eps);
+    else
+      hipLaunchKernelGGL(splitk_reduce_norm_kernel<1>, dim3(M), dim3(256), 0, stream, g_ws, bias, residual, H, norm_w, norm_b,
+                         (bf16_t*)Y, N, (long)ldr, (long)ldh, ldy, (long)M * N, sp, eps);
     MH_CHECK_LAUNCH();
     return MH_OK;
   }
-  int rc = mh_gemm_bf16_nt(A, lda, B, ldb, H, ldh, M, N, K, nullptr, residual, ldr, MH_GEMM_OUT_F32, 1.0f, stream);
+  int rc = mh_gemm_bf16_nt(A, lda, B, ldb, H, ldh, M, N, K, bias, residual, ldr, MH_GEMM_OUT_F32, 1.0f, stream);
   if (rc) return rc;
-  if (ldh != N) return MH_ERR_ARG;                  // rmsnorm_fwd reads a dense [M, N] stream
-  return mh_rmsnorm_fwd(H, norm_w, Y, ldy, M, N, eps, stream);
+  if (ldh != N) return MH_ERR_ARG;                  // the norm kernels read a dense [M, N] stream
+  if (norm == 0) return mh_rmsnorm_fwd(H, norm_w, Y, ldy, M, N, eps, stream);
+  return mh_layernorm_fwd(H, norm_w, norm_b, Y, nullptr, M, N, eps, stream);
+}
+
+extern "C" int mh_gemm_residual_rmsnorm(const void* A, int lda, const void* B, int ldb, float* H, int ldh,
+                                        const float* residual, int ldr, const float* norm_w, float eps, void* Y, long ldy,
+                                        int M, int N, int K, hipStream_t stream) {
+  return gemm_residual_norm(0, A, lda, B, ldb, H, ldh, nullptr, residual, ldr, norm_w, nullptr, eps, Y, ldy, M, N, K, stream);
+}
+
+extern "C" int mh_gemm_residual_layernorm(const void* A, int lda, const void* B, int ldb, float* H, int ldh, const float* bias,
+                                          const float* residual, int ldr, const float* norm_w, const float* norm_b, float eps,
+                                          void* Y, int M, int N, int K, hipStream_t stream) {
+  return gemm_residual_norm(1, A, lda, B, ldb, H, ldh, bias, residual, ldr, norm_w, norm_b, eps, Y, N, M, N, K, stream);
 }
 
 // ---- explicit split-K entry (wgrad of the conv stem: M,N small, K huge); caller passes the scratch ----

@@ -82,13 +82,19 @@ class EvaViTHIP:
         M = B * N
         h = x.view(M, D)
         scale = hd ** -0.5
-        for blk in self.blocks:
-            xn, _ = ops.layernorm_fwd(h, blk["n1w"], blk["n1b"], self.eps)
+        # each LayerNorm rides the split-K reduce of the GEMM that produces its input when that GEMM is split
+        # (ops.gemm_residual_layernorm: fc2 -> next block's norm1, proj -> norm2); only block 0's norm1 is its own launch
+        nb = len(self.blocks)
+        xn = ops.layernorm_fwd(h, self.blocks[0]["n1w"], self.blocks[0]["n1b"], self.eps)[0] if nb else None
+        for bi, blk in enumerate(self.blocks):
             qkv = ops.gemm(xn, blk["wqkv"], bias=blk["bqkv"]).view(B, N, 3 * D)
             o, _ = ops.attn_fwd(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], H, hd, scale, bias=rel_pos_bias,
                                 need_lse=False)
-            h = ops.gemm(o.view(M, D), blk["wproj"], bias=blk["bproj"], residual=h, out_dtype=F32)
-            xn, _ = ops.layernorm_fwd(h, blk["n2w"], blk["n2b"], self.eps)
+            h, xn = ops.gemm_residual_layernorm(o.view(M, D), blk["wproj"], blk["bproj"], h, blk["n2w"], blk["n2b"], self.eps)
             a = ops.gemm(xn, blk["w1"], bias=blk["b1"], gelu=True)
-            h = ops.gemm(a, blk["w2"], bias=blk["b2"], residual=h, out_dtype=F32)
+            if bi + 1 < nb:
+                nxt = self.blocks[bi + 1]
+                h, xn = ops.gemm_residual_layernorm(a, blk["w2"], blk["b2"], h, nxt["n1w"], nxt["n1b"], self.eps)
+            else:
+                h = ops.gemm(a, blk["w2"], bias=blk["b2"], residual=h, out_dtype=F32)
         return h.view(B, N, D)

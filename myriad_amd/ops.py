@@ -520,3 +520,19 @@ def gemm_residual_rmsnorm(a: torch.Tensor, b: torch.Tensor, residual: torch.Tens
                                        _p(norm_w), float(eps), _p(y), y.stride(0), M, N, K, _s())
     _lib.check(rc, f"mh_gemm_residual_rmsnorm M={M} N={N} K={K}")
     return h, y
+
+
+def gemm_residual_layernorm(a: torch.Tensor, b: torch.Tensor, bias: Optional[torch.Tensor], residual: torch.Tensor,
+                            norm_w: torch.Tensor, norm_b: torch.Tensor, eps: float):
+    """(h, y): h = a @ b^T + bias + residual (f32), y = layernorm(h) * norm_w + norm_b (bf16).  Pre-LN ViT blocks."""
+    _chk2d(a, BF16, "gemm_residual_layernorm.a")
+    _chk2d(b, BF16, "gemm_residual_layernorm.b")
+    _chk2d(residual, F32, "gemm_residual_layernorm.residual")
+    M, K = a.shape
+    N = b.shape[0]
+    h = torch.empty((M, N), dtype=F32, device=a.device)
+    y = torch.empty((M, N), dtype=BF16, device=a.device)
+    rc = _L().mh_gemm_residual_layernorm(_p(a), a.stride(0), _p(b), b.stride(0), _p(h), N, _p(bias), _p(residual),
+                                         residual.stride(0), _p(norm_w), _p(norm_b), float(eps), _p(y), M, N, K, _s())
+    _lib.check(rc, f"mh_gemm_residual_layernorm M={M} N={N} K={K}")
+    return h, y

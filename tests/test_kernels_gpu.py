@@ -136,6 +136,22 @@ def test_gemm_residual_rmsnorm_is_bit_identical_to_two_launches(M, N, K):
     assert relerr(h, a.float() @ b.float().T + res) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(2056, 1408, 6144), (2056, 1408, 1408), (300, 512, 256)])
+def test_gemm_residual_layernorm_is_bit_identical_to_two_launches(M, N, K):
+    ops.ensure_workspace(DEV)
+    a = bf(rnd(M, K, seed=41)).to(DEV)
+    b = bf(rnd(N, K, seed=42) * 0.05).to(DEV)
+    bias = rnd(N, seed=43).to(DEV)
+    res = rnd(M, N, seed=44).to(DEV)
+    w, nb = (1 + 0.1 * rnd(N, seed=45)).to(DEV), (0.1 * rnd(N, seed=46)).to(DEV)
+    h_ref = ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32)
+    y_ref, _ = ops.layernorm_fwd(h_ref, w, nb, 1e-6)
+    h, y = ops.gemm_residual_layernorm(a, b, bias, res, w, nb, 1e-6)
+    assert torch.equal(h, h_ref) and torch.equal(y, y_ref)
+    ref = torch.nn.functional.layer_norm(a.float() @ b.float().T + bias + res, (N,), w, nb, 1e-6)
+    assert relerr(y.float(), ref) < 1e-2
+
+
 def test_gemm_rejects_bad_k():
     a = bf(rnd(8, 40)).to(DEV)
     b = bf(rnd(8, 40)).to(DEV)

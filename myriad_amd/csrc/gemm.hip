@@ -461,6 +461,16 @@ static int auto_splits(int M, int N, int K) {
   const long tiles = (long)((M + BM - 1) / BM) * ((N + 127) / 128);
   const int kt = K / 64;
   if (N % 4) return 1;
+  if (M <= 512) {
+    // skinny M (batch-1 step: 148 LLaMA rows, 257 ViT rows): the launch streams the weight matrix once and the only
+    // question is whether enough workgroups are streaming -- aim at ~512 of them, at least 256 of K each.  Measured
+    // (tools/gemm_skinny_sweep.py, cold weights): 148x4096x22016 288 -> 62 us at s = 8, 148x4096x4096 60 -> 22 us,
+    // 257x1408x6144 86 -> 23 us; the reduce pass is small because M is.
+    int s = (int)(512 / (tiles > 0 ? tiles : 1));
+    s = s < 1 ? 1 : (s > 16 ? 16 : s);
+    while (s > 1 && kt / s < 4) --s;
+    return s;
+  }
   if (tiles >= 256 && tiles < 400 && kt >= 128) return 3;
   if (tiles >= 128 && tiles < 256 && kt >= 64) return 2;
   if (tiles < 64 && kt >= 48) return 4;

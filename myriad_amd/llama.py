@@ -75,6 +75,7 @@ class LlamaHIP:
             self.lm_headT = lmT
         inv_freq = 1.0 / (10000.0 ** (torch.arange(0, self.hd, 2).float() / self.hd))
         fr = torch.einsum("i,j->ij", torch.arange(max_pos).float(), inv_freq)
+        self._pos_cache = {}
         self.cos = fr.cos().contiguous().to(self.dev)
         self.sin = fr.sin().contiguous().to(self.dev)
         self._saved = None
@@ -98,8 +99,8 @@ class LlamaHIP:
         kv_len_host = am.sum(-1).to(torch.int32)
         if not bool((am == (torch.arange(S)[None] < kv_len_host[:, None])).all()):
             raise ValueError("attention_mask must be right-padded (ones then zeros), as the reference builds it")
-        kv_len = kv_len_host.to(self.dev)
-        pos = torch.arange(S, dtype=torch.int32).repeat(B).to(self.dev)  # position_ids = arange (modeling_llama.py:519-523)
+        kv_len = ops.h2d(kv_len_host, self.dev)                         # async uploads: no launch-thread stall
+        pos = self._pos_ids(B, S)                                       # position_ids = arange (modeling_llama.py:519-523)
         scale = 1.0 / math.sqrt(hd)
         h = x.reshape(M, D)
         saved = []
@@ -143,8 +144,8 @@ class LlamaHIP:
         lab = labels.to("cpu")
         shift = lab[:, 1:]
         bi, si = torch.nonzero(shift != -100, as_tuple=True)
-        rows = (bi * S + si).to(torch.int32).to(self.dev)
-        tgt = shift[bi, si].to(self.dev)
+        rows = ops.h2d((bi * S + si).to(torch.int32), self.dev)
+        tgt = ops.h2d(shift[bi, si], self.dev)
         n_valid = int(rows.numel())
         if n_valid == 0:
             raise ValueError("no valid labels")
@@ -198,7 +199,12 @@ class LlamaHIP:
         self._saved = None
         return dh.view(B, S, D)
 
-    # ------------------------------------------------------------------ generation
+    def _pos_ids(self, B: int, S: int) -> torch.Tensor:
+        key = (B, S)
+        if key not in self._pos_cache:
+            self._pos_cache[key] = torch.arange(S, dtype=torch.int32).repeat(B).to(self.dev)
+        return self._pos_cache[key]
+
     # ------------------------------------------------------------------ generation
     def _decode_block(self, h, B, S, caches, scale, pos, past=None, pos_dev=None, kvlen_dev=None):
         """All decoder layers for a prefill chunk (host-known `past`) or for one decode token whose position lives

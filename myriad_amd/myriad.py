@@ -319,8 +319,8 @@ class MyriadHIP(nn.Module):
             ids.append(after[b]); rows.append(base + 1 + nb + n_img + torch.arange(na))
             if T:
                 ids.append(tgt[b]); rows.append(base + 1 + nb + n_img + na + torch.arange(T))
-        ids = torch.cat(ids).long().to(self._dev)
-        rows = torch.cat(rows).int().to(self._dev)
+        ids = ops.h2d(torch.cat(ids).long(), self._dev)
+        rows = ops.h2d(torch.cat(rows).int(), self._dev)
         self.llama.embed_tokens_into(ids, emb.view(B * S, self.Dl), rows)
         attn = labels = None
         if T:

@@ -92,15 +92,30 @@ class GemmProbe:
                 out.element_size() + (4 if kw.get("residual") is not None else 0))
             return out
 
-        ops.gemm = timed
-        for mod in ("llama", "qformer", "eva_vit", "networks", "myriad"):
-            m = sys.modules.get("myriad_amd." + mod)
-            if m is not None and hasattr(m, "ops"):
-                pass   # modules call ops.gemm through the module attribute, so patching ops is enough
+        def timed_fused(orig):
+            # Linear + residual + norm entry points (mh_gemm_residual_rmsnorm / _layernorm): GEMM kernel + one more launch
+            def f(a, b, *args, **kw):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = orig(a, b, *args, **kw)
+                e1.record()
+                shp = (a.shape[0], b.shape[0], a.shape[1])
+                self.records.append((e0, e1, 2.0 * shp[0] * shp[1] * shp[2], shp))
+                self.fused.add(shp)
+                self.bytes[shp] = self.bytes.get(shp, 0.0) + 2.0 * (shp[0] + shp[1]) * shp[2] + shp[0] * shp[1] * (4 + 4 + 2)
+                return out
+            return f
+
+        self.fused = set()
+        self.orig_fused = (ops.gemm_residual_rmsnorm, ops.gemm_residual_layernorm)
+        ops.gemm = timed                     # modules call ops.* through the module attribute, so patching ops is enough
+        ops.gemm_residual_rmsnorm = timed_fused(self.orig_fused[0])
+        ops.gemm_residual_layernorm = timed_fused(self.orig_fused[1])
         return self
 
     def __exit__(self, *exc):
         self.ops.gemm = self.orig
+        self.ops.gemm_residual_rmsnorm, self.ops.gemm_residual_layernorm = self.orig_fused
 
     def summary(self):
         torch.cuda.synchronize()
@@ -118,7 +133,8 @@ class GemmProbe:
         per = {}
         for shp, (cnt, ms, f) in shapes.items():
             kid, splits = self.ops.gemm_plan(*shp)
-            key = (self.ops.GEMM_KERNEL_NAMES[kid], "split" if splits > 1 else "plain")
+            # "plain" = exactly one kernel inside the event pair; everything else carries a reduce and/or norm launch
+            key = (self.ops.GEMM_KERNEL_NAMES[kid], "split" if splits > 1 else ("plain+norm" if shp in self.fused else "plain"))
             d = per.setdefault(key, [0, 0.0, 0.0, 0.0])
             d[0] += cnt
             d[1] += ms

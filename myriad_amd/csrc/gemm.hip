@@ -15,6 +15,8 @@
 // ds_read_b128 fragment reads.  The MFMA is issued as (B-frag, A-frag) so each lane ends up with 4 consecutive N
 // for one M row -> 8/16-byte vector epilogue stores with vector bias/residual loads.  Workgroup ids are remapped so
 // each XCD (private L2) owns a contiguous run of tiles that share the same weight panel.
+#include <cstdlib>
+
 #include "common.h"
 
 #define BM 128
@@ -279,6 +281,10 @@ int mh_launch_gemm_256(const void* A, int lda, const void* B, int ldb, void* C, 
                        const float* bias, const float* residual, int ldr, int flags, float alpha, int splits, int tps,
                        long split_stride, hipStream_t stream);
 
+int mh_launch_gemm_stream(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
+                          const float* bias, const float* residual, int ldr, int flags, float alpha, int splits,
+                          int steps_per_split, long split_stride, hipStream_t stream);
+
 static int dispatch(const GemmArgs& g, hipStream_t stream) {
   int variant = (g.flags >> MH_GEMM_VARIANT_SHIFT) & 15;
   if (g.flags & MH_GEMM_REGSTAGE) return launch_gemm<1, 2, 128, 2>(g, stream);
@@ -300,6 +306,9 @@ static int dispatch(const GemmArgs& g, hipStream_t stream) {
     case 12:                                                      // 256x256x32, 4-deep ring (gemm_256.hip), 1 block/CU
       return mh_launch_gemm_256(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, g.bias, g.residual, g.ldr, g.flags,
                                 g.alpha, g.splits, g.tps, g.split_stride, stream);
+    case 13:                                                      // mid-M weight streaming (gemm_stream.hip)
+      return mh_launch_gemm_stream(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, g.bias, g.residual, g.ldr, g.flags,
+                                   g.alpha, g.splits, g.tps, g.split_stride, stream);
     default: return MH_ERR_ARG;
   }
 }
@@ -433,6 +442,9 @@ static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t str
   else if (((g0.flags >> MH_GEMM_VARIANT_SHIFT) & 15) == 11)
     rc = mh_launch_gemm_pp(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, nullptr, nullptr, 0, g.flags, 1.0f,
                            g.splits, g.tps, g.split_stride, stream);
+  else if (((g0.flags >> MH_GEMM_VARIANT_SHIFT) & 15) == 13)
+    rc = mh_launch_gemm_stream(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, nullptr, nullptr, 0, g.flags, 1.0f,
+                               g.splits, g.tps, g.split_stride, stream);
   else
     rc = launch_gemm<0, 2, 128, 2>(g, stream);
   if (rc) return rc;
@@ -493,11 +505,33 @@ static int big_tile_splits(int M, int N, int K, int tile_n) {
   return best;
 }
 
+// mid-M streaming kernel: one 8-wave workgroup per 256 weight rows and K slice, one workgroup per CU (its activation ring
+// takes 96-120 KiB of LDS): as many K slices as fit one round of 256 workgroups, at least 4 steps of 64 each
+static int stream_splits(int M, int N, int K) {
+  (void)M;
+  const int blocks_n = (N + 255) / 256, steps = K / 64;
+  int s = 256 / blocks_n;
+  s = s < 1 ? 1 : (s > 16 ? 16 : s);
+  while (s > 1 && steps / s < 4) --s;
+  return s;
+}
+
+static int stream_enabled() {
+  static int on = -1;
+  if (on < 0) {
+    const char* e = getenv("MYRIAD_GEMM_STREAM");
+    on = (e && e[0] == '1') ? 1 : 0;              // off by default: at parity with the tile kernels, not ahead
+  }
+  return on;
+}
+
 // The automatic policy (flags carry no variant): which kernel runs and with how many K splits.
 //   kernel 0: gemv.hip weight streaming (M <= 16: decode)
 //   kernel 2: gemm_256.hip 256x256 tile, when it can put >= 128 workgroups on the chip with >= 1024 of K each
 //             (+20..26 % over the 128x128 kernel on the step's LLaMA / ViT shapes, cold weights,
 //             profiles/r01_gemm_256.md)
+//   kernel 3: gemm_stream.hip weight streaming with shared activation rows (16 < M <= 288); only with
+//             MYRIAD_GEMM_STREAM=1 -- measured at parity with kernels 1 / 2 on the batch-1 step, so not the default
 //   kernel 1: the 128x128 kernel for everything smaller -- it co-schedules two workgroups per CU and so hides its
 //             own prologue / store tail, which the one-workgroup-per-CU 256x256 kernel cannot
 static void gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits) {
@@ -506,6 +540,11 @@ static void gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits) 
   if (M <= 16 && !(flags & (MH_GEMM_REGSTAGE | MH_GEMM_GELU))) { *kernel = 0; return; }
   if (flags & MH_GEMM_REGSTAGE) return;
   const bool can_split = g_ws && (N % 4) == 0;
+  if (M <= 288 && (N % 4) == 0 && stream_enabled()) {
+    int s = can_split ? stream_splits(M, N, K) : 1;
+    while (s > 1 && (size_t)s * M * N * sizeof(float) > g_ws_bytes) --s;
+    *kernel = 3; *splits = s; return;
+  }
   if (M > 128) {
     const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
     int s = can_split ? big_tile_splits(M, N, K, 256) : 1;
@@ -540,6 +579,11 @@ extern "C" int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
       return mh_launch_gemv(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, (flags & MH_GEMM_OUT_F32) ? 1 : 0,
                             alpha, stream);
     if (kernel == 2) g.flags |= 12 << MH_GEMM_VARIANT_SHIFT;
+    if (kernel == 3) {
+      // 16-byte epilogue accesses: an oddly aligned bias / residual view goes to the 128x128 kernel instead
+      if (((uintptr_t)bias & 15) || ((uintptr_t)residual & 15)) splits = 1;
+      else g.flags |= 13 << MH_GEMM_VARIANT_SHIFT;
+    }
     // the split-K reduce reads `residual` and writes C element-wise, so C may alias residual (in-place accumulate)
     return splits > 1 ? run_splitk(g, splits, g_ws, stream) : dispatch(g, stream);
   }
@@ -547,6 +591,13 @@ extern "C" int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
   if ((variant == 11 || variant == 12) && g_ws && (N % 4) == 0) {
     const int best = big_tile_splits(M, N, K, variant == 12 ? 256 : 128);
     if (best > 1 && (size_t)best * M * N * sizeof(float) <= g_ws_bytes) return run_splitk(g, best, g_ws, stream);
+  }
+  if (variant == 13) {
+    if (M > 288 || (N % 4) != 0 || ((uintptr_t)bias & 15) || ((uintptr_t)residual & 15)) return MH_ERR_UNSUPPORTED;
+    int s = g_ws ? stream_splits(M, N, K) : 1;
+    if (const char* e = getenv("MYRIAD_STREAM_SPLITS")) s = atoi(e) > 0 && g_ws ? atoi(e) : s;
+    while (s > 1 && (size_t)s * M * N * sizeof(float) > g_ws_bytes) --s;
+    if (s > 1) return run_splitk(g, s, g_ws, stream);
   }
   return dispatch(g, stream);
 }
@@ -567,6 +618,7 @@ static int gemm_residual_norm(int norm, const void* A, int lda, const void* B, i
       (lda % 8) == 0 && (ldb % 8) == 0 && !(((uintptr_t)A | (uintptr_t)B | (uintptr_t)H) & 15)) {
     GemmArgs g = {A, lda, B, ldb, (void*)H, ldh, M, N, K, nullptr, residual, ldr, MH_GEMM_OUT_F32, 1.0f, 1, K / 64, 0L};
     if (kernel == 2) g.flags |= 12 << MH_GEMM_VARIANT_SHIFT;
+    if (kernel == 3) g.flags |= 13 << MH_GEMM_VARIANT_SHIFT;
     const int nt = K / 64;                          // the split count run_splitk will settle on
     int sp = splits > nt ? nt : splits;
     const int tps = (nt + sp - 1) / sp;

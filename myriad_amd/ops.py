@@ -97,6 +97,13 @@ def ensure_workspace(device, nbytes: int = 256 << 20):
     return _WS[key]
 
 
+def drop_workspace():
+    """Unregister the split-K scratch (tests: the no-workspace paths).  ensure_workspace() registers it again."""
+    torch.cuda.synchronize()
+    _lib.check(_L().mh_set_workspace(None, 0), "mh_set_workspace")
+    _WS.clear()
+
+
 def round_up(x: int, m: int) -> int:
     return (x + m - 1) // m * m
 
@@ -132,7 +139,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, b
     return out
 
 
-GEMM_KERNEL_NAMES = {0: "gemv_kernel", 1: "gemm_nt_kernel", 2: "gemm_256_kernel"}
+GEMM_KERNEL_NAMES = {0: "gemv_kernel", 1: "gemm_nt_kernel", 2: "gemm_256_kernel", 3: "gemm_stream_kernel"}
 
 
 def gemm_plan(M: int, N: int, K: int, out_f32: bool = False, gelu: bool = False):

@@ -118,7 +118,45 @@ def test_skinny_m_weight_streaming_gemm(M, N, K):
     assert relerr(ops.gemm(a, b, out_dtype=torch.float32), ops.gemm(a, b, out_dtype=torch.float32, variant=1)) < 1e-4
 
 
-@pytest.mark.parametrize("M,N,K", [(1184, 4096, 4096), (1184, 4096, 11008), (300, 512, 256), (2056, 1408, 6144)])
+@pytest.mark.parametrize("ws", [True, False])
+@pytest.mark.parametrize("M,N,K", [(148, 4096, 4096), (148, 12352, 4160), (257, 1408, 6144), (17, 1000, 11008), (288, 4224, 1408),
+                                   (60, 32000, 4096), (148, 136, 64), (33, 72, 448)])
+def test_mid_m_weight_streaming_gemm(M, N, K, ws):
+    """16 < M <= 288 (the batch-1 step, prefill) forced onto gemm_stream.hip (variant 13): five-wave workgroups, weights
+    straight to registers, activation rows through the LDS ring; with a workspace K is split and the epilogue moves to the
+    reduce pass.  Every epilogue, strided operands, ragged N and the 1-step / tail-step K loops."""
+    if ws:
+        ops.ensure_workspace(DEV)
+    else:
+        ops.drop_workspace()
+    try:
+        a_full = bf(rnd(M, K + 64, seed=51)).to(DEV)
+        a = a_full[:, :K]
+        b = bf(rnd(N, K, seed=52) * 0.05 + torch.arange(N)[:, None] * 1e-4).to(DEV)
+        bias = rnd(N, seed=53).to(DEV)
+        res = rnd(M, N, seed=54).to(DEV)
+        ref = a.float() @ b.float().T
+        tol = 2e-5 * math.sqrt(K) + 1e-5
+        assert relerr(ops.gemm(a, b, out_dtype=torch.float32, variant=13), ref) < tol
+        assert relerr(ops.gemm(a, b, variant=13).float(), ref) < 6e-3
+        o = ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32, alpha=0.5, variant=13)
+        assert relerr(o, 0.5 * ref + bias + res) < tol
+        og = ops.gemm(a, b, bias=bias, gelu=True, variant=13)
+        assert relerr(og.float(), F.gelu(ref + bias)) < 6e-3
+        acc = res.clone()
+        ops.gemm(a, b, out=acc, residual=acc, variant=13)
+        assert relerr(acc, ref + res) < tol
+        wide = torch.zeros(M, N + 72, dtype=torch.bfloat16, device=DEV)
+        ops.gemm(a, b, out=wide[:, 8:8 + N], variant=13)
+        assert relerr(wide[:, 8:8 + N].float(), ref) < 6e-3
+        assert wide[:, :8].abs().max() == 0 and wide[:, 8 + N:].abs().max() == 0
+        # against the 128x128 kernel on the same operands
+        assert relerr(ops.gemm(a, b, out_dtype=torch.float32, variant=13), ops.gemm(a, b, out_dtype=torch.float32, variant=1)) < 1e-4
+    finally:
+        ops.ensure_workspace(DEV)
+
+
+@pytest.mark.parametrize("M,N,K", [(1184, 4096, 4096), (1184, 4096, 11008), (300, 512, 256), (2056, 1408, 6144), (148, 4096, 11008)])
 def test_gemm_residual_rmsnorm_is_bit_identical_to_two_launches(M, N, K):
     """Split-K reduce + residual add + RMSNorm in one kernel (split shapes) or GEMM then norm (the rest): same bits."""
     ops.ensure_workspace(DEV)

@@ -166,6 +166,14 @@ int mh_rope_kv_append(void* qkv, long ld, int n_heads, int head_dim, const int* 
                       const float* sin_tab, void* cache, long cache_bstride, long ld_cache, const int* pos_dev, int B,
                       mh_stream_t s);
 int mh_add_i32(int* x, int n, int delta, mh_stream_t s);
+/* Decode weight layout (modeling_llama.py:184-231 with the KV cache: every token multiplies <= 16 rows by every frozen
+ * Linear).  mh_gemv_pack writes a stream-ordered copy of W [N, K] bf16 (mh_gemv_pack_elems(N, K) elements, -1 on bad
+ * dims): the 16 B lane (lr, lg) of wave w reads at step t sit at ((block*NW + w)*per + t)*2 KiB + h*1 KiB + lane*16, so
+ * the skinny-M kernel reads each KiB contiguously.  mh_gemv_packed = mh_gemm_bf16_nt for M <= 16 on that copy, bit-identical. */
+long mh_gemv_pack_elems(int N, int K);
+int mh_gemv_pack(const void* W, int ldb, int N, int K, void* out, mh_stream_t s);
+int mh_gemv_packed(const void* A, int lda, const void* P, void* C, int ldc, int M, int N, int K, const float* bias,
+                   const float* residual, int ldr, int out_f32, float alpha, mh_stream_t s);
 /* K14 patch embedding operand (eva_vit.py:196-204): NCHW f32 image -> [B*np, Kpad] bf16 in (c,iy,ix) order */
 int mh_patchify_nchw(const float* img, void* out, int B, int C, int H, int W, int P, int Kpad, mh_stream_t s);
 int mh_scatter_rows_f32(const float* src, const int* rows, float* dst, long ldd, long n, int D, int accumulate,

@@ -52,6 +52,42 @@ __global__ __launch_bounds__(GV_NW * 64) void gemv_kernel(const bf16_t* __restri
       const short8_t xv = *reinterpret_cast<const short8_t*>(xp + k);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xv, wv, acc, 0, 0, 0);
     }
+  } else if (MODE == 2) {
+    // MODE 1's arithmetic on a pre-permuted weight copy (mh_gemv_pack): the bytes lane (lr, lg) of wave w needs at step t
+    // sit at ((block * NW + w) * per + t) * 2 KiB + h * 1 KiB + lane * 16, so every wave-instruction reads one contiguous
+    // KiB and a wave walks one contiguous region -- 6.8 TB/s against 5.8 TB/s for the row-strided order on a pure stream
+    // (tools/micro/stream_pattern.hip), and bit-identical results (same k per lane, same reduction order).
+    const bf16_t* xp = A + (size_t)mrow * lda + lg * 16;
+    const int nsteps = K / 64;
+    const int per = (nsteps + GV_NW - 1) / GV_NW;
+    const bf16_t* wp = B + ((size_t)blockIdx.x * GV_NW + wave) * per * 1024 + lane * 8;
+    int s = wave * per;
+    const int s0 = s;
+    const int s_end = (s + per) < nsteps ? (s + per) : nsteps;
+    for (; s + UNROLL <= s_end; s += UNROLL) {
+      short8_t w0[UNROLL], w1[UNROLL], x0[UNROLL], x1[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        const int k = (s + u) * 64;
+        w0[u] = __builtin_nontemporal_load(reinterpret_cast<const short8_t*>(wp + (size_t)(s - s0 + u) * 1024));
+        w1[u] = __builtin_nontemporal_load(reinterpret_cast<const short8_t*>(wp + (size_t)(s - s0 + u) * 1024 + 512));
+        x0[u] = *reinterpret_cast<const short8_t*>(xp + k);
+        x1[u] = *reinterpret_cast<const short8_t*>(xp + k + 8);
+      }
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0[u], w0[u], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1[u], w1[u], acc, 0, 0, 0);
+      }
+    }
+    for (; s < s_end; ++s) {
+      const int k = s * 64;
+      const short8_t w0 = *reinterpret_cast<const short8_t*>(wp + (size_t)(s - s0) * 1024);
+      const short8_t w1 = *reinterpret_cast<const short8_t*>(wp + (size_t)(s - s0) * 1024 + 512);
+      const short8_t x0 = *reinterpret_cast<const short8_t*>(xp + k), x1 = *reinterpret_cast<const short8_t*>(xp + k + 8);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, w0, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w1, acc, 0, 0, 0);
+    }
   } else {
     // 64-deep steps, lane holds k = 16*lg .. 16*lg+15 (32 contiguous bytes); wave w owns the contiguous K quarter
     // [w*K/4, (w+1)*K/4) rounded to steps, so each wave walks 16 rows line by line
@@ -130,6 +166,62 @@ int mh_launch_gemv(const void* A, int lda, const void* B, int ldb, void* C, int 
   else if (small && nw_small == 16) GV_LAUNCH(1, 4, 16);
   else GV_LAUNCH(1, 8, 4);
 #undef GV_LAUNCH
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// ---- stream-ordered weight copy for decode (288 GB of HBM: a second, 13.5 GB copy of the frozen LLaMA weights is cheap) ----
+static inline int gv_packed_nw(int N) { return ((N + 15) / 16 < 512) ? 8 : 4; }   // the launch rule above, without the env knob
+
+__global__ void gemv_pack_kernel(const bf16_t* __restrict__ W, int ldb, int N, int K, bf16_t* __restrict__ out, int nw, int per,
+                                 long chunks) {
+  const int nsteps = K / 64;
+  for (long c = blockIdx.x * (long)blockDim.x + threadIdx.x; c < chunks; c += (long)gridDim.x * blockDim.x) {
+    const int lane = (int)(c & 63), h = (int)((c >> 6) & 1);
+    long r = c >> 7;
+    const int t = (int)(r % per); r /= per;
+    const int q = (int)(r % nw);
+    const long nb = r / nw;
+    const int lr = lane & 15, lg = lane >> 4;
+    long row = nb * 16 + lr;
+    row = row < N ? row : N - 1;
+    const int step = q * per + t;
+    short8_t v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (step < nsteps) v = *reinterpret_cast<const short8_t*>(W + row * ldb + step * 64 + lg * 16 + h * 8);
+    *reinterpret_cast<short8_t*>(out + c * 8) = v;
+  }
+}
+
+extern "C" long mh_gemv_pack_elems(int N, int K) {
+  if (N <= 0 || K <= 0 || (K % 64) != 0) return -1;
+  const int nw = gv_packed_nw(N), per = (K / 64 + nw - 1) / nw;
+  return (long)((N + 15) / 16) * nw * per * 1024;
+}
+
+extern "C" int mh_gemv_pack(const void* W, int ldb, int N, int K, void* out, hipStream_t stream) {
+  if (N <= 0 || K <= 0 || (K % 64) != 0 || (ldb % 8) != 0 || ((uintptr_t)W & 15) || ((uintptr_t)out & 15)) return MH_ERR_ARG;
+  const int nw = gv_packed_nw(N), per = (K / 64 + nw - 1) / nw;
+  const long chunks = (long)((N + 15) / 16) * nw * per * 128;
+  long grid = (chunks + 255) / 256;
+  if (grid > 65536) grid = 65536;
+  hipLaunchKernelGGL(gemv_pack_kernel, dim3((int)grid), dim3(256), 0, stream, (const bf16_t*)W, ldb, N, K, (bf16_t*)out, nw, per,
+                     chunks);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// C[M <= 16, N] = alpha * A . W^T (+bias) (+residual) with W given as its mh_gemv_pack copy
+extern "C" int mh_gemv_packed(const void* A, int lda, const void* P, void* C, int ldc, int M, int N, int K, const float* bias,
+                              const float* residual, int ldr, int out_f32, float alpha, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return MH_OK;
+  if (M > 16 || K <= 0 || (K % 64) != 0 || (lda % 8) != 0 || ((uintptr_t)A & 15) || ((uintptr_t)P & 15)) return MH_ERR_ARG;
+  const dim3 grid((N + 15) / 16);
+  if (gv_packed_nw(N) == 8)
+    hipLaunchKernelGGL((gemv_kernel<2, 8, 8>), grid, dim3(512), 0, stream, (const bf16_t*)A, (const bf16_t*)P, C, bias, residual, M,
+                       N, K, lda, 0, ldc, ldr, out_f32, alpha);
+  else
+    hipLaunchKernelGGL((gemv_kernel<2, 8, 4>), grid, dim3(256), 0, stream, (const bf16_t*)A, (const bf16_t*)P, C, bias, residual, M,
+                       N, K, lda, 0, ldc, ldr, out_f32, alpha);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

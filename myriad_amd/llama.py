@@ -13,6 +13,7 @@ the clamp-CE loss run only on label-bearing rows (the other rows have zero gradi
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -80,6 +81,22 @@ class LlamaHIP:
         self.sin = fr.sin().contiguous().to(self.dev)
         self._saved = None
         self.lora = None
+        # decode keeps a second, stream-ordered copy of the frozen weights (ops.gemv_pack; +1x the LLM's bf16 bytes, 13.5 GB
+        # for Vicuna-7B out of 288 GB) built at the first generate(); MYRIAD_PACK_DECODE=0 streams the row-major ones
+        self.pack_decode = os.environ.get("MYRIAD_PACK_DECODE", "1") != "0"
+        self._packed = None
+
+    def _pack_for_decode(self) -> None:
+        """(Re)build the packed copies the single-token step streams.  Frozen matrices are packed once; the bordered qkv
+        weight carries the LoRA B columns, which training moves, so it is re-packed (in place) at every generate()."""
+        qkv_key = "wqkv" if self.lora is None else "wqkv_ext"
+        if self._packed is None:
+            self._packed = dict(layers=[{k: ops.gemv_pack(L[k]) for k in ("wo", "wgu", "wd")} for L in self.layers],
+                                lm_head=ops.gemv_pack(self.lm_head), qkv_key=None)
+        if self._packed["qkv_key"] != qkv_key or self.lora is not None:
+            for L, P in zip(self.layers, self._packed["layers"]):
+                P["wqkv"] = ops.gemv_pack(L[qkv_key], out=P.get("wqkv") if self._packed["qkv_key"] == qkv_key else None)
+            self._packed["qkv_key"] = qkv_key
 
     def attach_lora(self, lora) -> None:
         """Enable PEFT-style LoRA on q_proj/v_proj (myriad_amd.lora.LoraQV); replaces W_qkv by its bordered copy."""
@@ -211,15 +228,22 @@ class LlamaHIP:
         in device memory (`pos_dev`/`kvlen_dev`), which makes the launch sequence replayable from a hipGraph."""
         H, hd, W, D = self.H, self.hd, self.D, self.D
         M = B * S
+        packed = self._packed["layers"] if (pos_dev is not None and M <= 16 and self._packed is not None) else None
+
+        def lin(li, name, x, **kw):
+            if packed is not None:
+                return ops.gemv_packed(x, packed[li]["wqkv" if name.startswith("wqkv") else name], **kw)
+            return ops.gemm(x, self.layers[li][name], **kw)
+
         for li, (L, cache) in enumerate(zip(self.layers, caches)):
             if self.lora is None:
                 xn = ops.rmsnorm_fwd(h, L["ln1"], self.eps)
-                qkv = ops.gemm(xn, L["wqkv"])
+                qkv = lin(li, "wqkv", xn)
             else:
                 x_ext = self.lora.x_ext(li, M)
                 ops.rmsnorm_fwd(h, L["ln1"], self.eps, out=x_ext[:, :D])
                 self.lora.forward_border(li, x_ext, training=False)
-                qkv = ops.gemm(x_ext, L["wqkv_ext"])
+                qkv = lin(li, "wqkv_ext", x_ext)
             q3 = qkv.view(B, S, 3 * W)
             if pos_dev is None:
                 ops.rope_(qkv, 0, 2 * H, hd, pos, self.cos, self.sin, 1.0)
@@ -230,10 +254,10 @@ class LlamaHIP:
                 ops.rope_kv_append(qkv, H, hd, pos, self.cos, self.sin, cache, pos_dev)   # rotary + append, one launch
                 o, _ = ops.attn_fwd(q3[:, :, :W], cache[:, :, :W], cache[:, :, W:], H, hd, scale, causal=False,
                                     kv_len=kvlen_dev, need_lse=False)
-            h2 = ops.gemm(o.view(M, W), L["wo"], residual=h, out_dtype=F32)
+            h2 = lin(li, "wo", o.view(M, W), residual=h, out_dtype=F32)
             xn2 = ops.rmsnorm_fwd(h2, L["ln2"], self.eps)
-            act = ops.silu_mul_fwd(ops.gemm(xn2, L["wgu"]))
-            h = ops.gemm(act, L["wd"], residual=h2, out_dtype=F32)
+            act = ops.silu_mul_fwd(lin(li, "wgu", xn2))
+            h = lin(li, "wd", act, residual=h2, out_dtype=F32)
         return h
 
     @torch.no_grad()
@@ -253,6 +277,10 @@ class LlamaHIP:
         unfinished = torch.ones(B, dtype=torch.long)
         if self.lora is not None:
             self.lora.refresh(self.layers)
+        if self.pack_decode and B <= 16:
+            self._pack_for_decode()
+        else:
+            self._packed = None
 
         def finish(logits, step):
             ban = eos_id if step < min_length else -1
@@ -289,7 +317,11 @@ class LlamaHIP:
         def token_step(ban):
             ops.embed_gather(self.embed, ids_dev, x_in)
             hh = self._decode_block(x_in, B, 1, caches, scale, pos_dev, pos_dev=pos_dev, kvlen_dev=kvlen_dev)
-            lg = ops.gemm(ops.rmsnorm_fwd(hh, self.norm, self.eps), self.lm_head, out_dtype=F32)
+            hn = ops.rmsnorm_fwd(hh, self.norm, self.eps)
+            if self._packed is not None:
+                lg = ops.gemv_packed(hn, self._packed["lm_head"], out_dtype=F32)
+            else:
+                lg = ops.gemm(hn, self.lm_head, out_dtype=F32)
             ops.argmax_rows(lg, ban_id=ban, want_margin=True, out=nxt_out, margin_out=mar_out)
             ops.add_i32_(pos_dev, 1)
             ops.add_i32_(kvlen_dev, 1)

@@ -151,6 +151,48 @@ def gemm_plan(M: int, N: int, K: int, out_f32: bool = False, gelu: bool = False)
     return kernel.value, splits.value
 
 
+class PackedWeight:
+    """Stream-ordered copy of a frozen [N, K] bf16 weight for the decode kernel (mh_gemv_pack)."""
+    __slots__ = ("data", "N", "K")
+
+    def __init__(self, data: torch.Tensor, N: int, K: int):
+        self.data, self.N, self.K = data, N, K
+
+
+def gemv_pack(w: torch.Tensor, out: Optional[PackedWeight] = None) -> PackedWeight:
+    """Permute w [N, K] into the order the skinny-M kernel streams it in; `out` re-uses an earlier copy's storage."""
+    _chk2d(w, BF16, "gemv_pack.w")
+    N, K = w.shape
+    n = _L().mh_gemv_pack_elems(N, K)
+    if n < 0:
+        raise _lib.MyriadHipError(f"gemv_pack: unsupported dims N={N} K={K}")
+    if out is None:
+        out = PackedWeight(torch.empty((n,), dtype=BF16, device=w.device), N, K)
+    elif (out.N, out.K) != (N, K):
+        raise _lib.MyriadHipError("gemv_pack: out was packed for another shape")
+    _lib.check(_L().mh_gemv_pack(_p(w), w.stride(0), N, K, _p(out.data), _s()), "mh_gemv_pack")
+    return out
+
+
+def gemv_packed(a: torch.Tensor, pw: PackedWeight, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
+                residual: Optional[torch.Tensor] = None, out_dtype=BF16, alpha: float = 1.0) -> torch.Tensor:
+    """out[M<=16, N] = alpha * a @ W^T (+bias) (+residual f32) with W given as its packed copy; same bits as gemm()."""
+    _chk2d(a, BF16, "gemv_packed.a")
+    M, K = a.shape
+    if K != pw.K or M > 16:
+        raise _lib.MyriadHipError(f"gemv_packed: a is {tuple(a.shape)}, weight was packed as [{pw.N}, {pw.K}], M must be <= 16")
+    if out is None:
+        out = torch.empty((M, pw.N), dtype=out_dtype, device=a.device)
+    ldr = 0
+    if residual is not None:
+        _chk2d(residual, F32, "gemv_packed.residual")
+        ldr = residual.stride(0)
+    rc = _L().mh_gemv_packed(_p(a), a.stride(0), _p(pw.data), _p(out), out.stride(0), M, pw.N, K, _p(bias), _p(residual), ldr,
+                             1 if out.dtype == F32 else 0, float(alpha), _s())
+    _lib.check(rc, f"mh_gemv_packed M={M} N={pw.N} K={K}")
+    return out
+
+
 def gemm_auto_f32(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     """f32 out = a @ b^T, choosing split-K when the output is small and the reduction long (wgrad shapes)."""
     M, K = a.shape

@@ -91,6 +91,16 @@ def test_graph_replayed_decode_equals_eager_decode(model):
         finally:
             L.LlamaHIP.greedy_generate = orig
         assert a.shape == (2, 12) and torch.equal(a, b)
+        # the single-token step streams packed weight copies by default; the row-major path must give the same tokens
+        llm = model.llama
+        assert llm._packed is not None and llm.pack_decode
+        llm.pack_decode = False
+        try:
+            d = model.generate(s, **kw)["token_ids"]
+            assert llm._packed is None
+        finally:
+            llm.pack_decode = True
+        assert torch.equal(a, d)
         c = model.generate(s, **dict(kw, max_new_tokens=1))["token_ids"]
         assert torch.equal(a[:, :1], c)                              # first token = arg-max of the prefill logits
     finally:

@@ -118,11 +118,36 @@ def test_skinny_m_weight_streaming_gemm(M, N, K):
     assert relerr(ops.gemm(a, b, out_dtype=torch.float32), ops.gemm(a, b, out_dtype=torch.float32, variant=1)) < 1e-4
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 12288, 4160), (16, 1000, 11008), (3, 32000, 4096), (2, 40, 192)])
+def test_decode_kernel_on_the_packed_weight_copy_is_bit_identical(M, N, K):
+    """mh_gemv_pack + mh_gemv_packed: the decode kernel streaming a pre-permuted copy of the weight (contiguous KiB per
+    wave-instruction) -- same k per lane and same reduction order, so the SAME bits as the row-major path, for ragged N
+    (1000, 40: padded blocks), a K that does not divide among the waves (4160 = 65 steps), bias / residual / f32 out."""
+    a = bf(rnd(M, K, seed=61)).to(DEV)
+    b_wide = bf(rnd(N, K + 64, seed=62) * 0.05 + torch.arange(N)[:, None] * 1e-4).to(DEV)
+    b = b_wide[:, :K]                                               # ldb > K
+    bias = rnd(N, seed=63).to(DEV)
+    res = rnd(M, N, seed=64).to(DEV)
+    pw = ops.gemv_pack(b)
+    assert pw.data.numel() >= N * K
+    assert torch.equal(ops.gemv_packed(a, pw), ops.gemm(a, b))
+    assert torch.equal(ops.gemv_packed(a, pw, out_dtype=torch.float32), ops.gemm(a, b, out_dtype=torch.float32))
+    got = ops.gemv_packed(a, pw, bias=bias, residual=res, out_dtype=torch.float32, alpha=0.5)
+    assert torch.equal(got, ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32, alpha=0.5))
+    assert relerr(got, 0.5 * (a.float() @ b.float().T) + bias + res) < 1e-4
+    # re-pack in place after the weight moved (the LoRA border of the qkv weight does between generate() calls)
+    b2 = bf(rnd(N, K, seed=65) * 0.05).to(DEV)
+    ops.gemv_pack(b2, out=pw)
+    assert torch.equal(ops.gemv_packed(a, pw), ops.gemm(a, b2))
+    with pytest.raises(RuntimeError):
+        ops.gemv_packed(bf(rnd(17, K)).to(DEV), pw)
+
+
 @pytest.mark.parametrize("ws", [True, False])
 @pytest.mark.parametrize("M,N,K", [(148, 4096, 4096), (148, 12352, 4160), (257, 1408, 6144), (17, 1000, 11008), (288, 4224, 1408),
                                    (60, 32000, 4096), (148, 136, 64), (33, 72, 448)])
 def test_mid_m_weight_streaming_gemm(M, N, K, ws):
-    """16 < M <= 288 (the batch-1 step, prefill) forced onto gemm_stream.hip (variant 13): five-wave workgroups, weights
+    """16 < M <= 288 (the batch-1 step, prefill) forced onto gemm_stream.hip (variant 13): 256 weight rows per workgroup, weights
     straight to registers, activation rows through the LDS ring; with a workspace K is split and the epilogue moves to the
     reduce pass.  Every epilogue, strided operands, ragged N and the 1-step / tail-step K loops."""
     if ws:

@@ -89,6 +89,35 @@ __global__ __launch_bounds__(512) void linear(const short* __restrict__ B, long 
   if (acc[0] == 12345 && acc[3] == 77) sink[0] = 1;
 }
 
+// the decode gemv's order: a workgroup owns 16 rows, its 4 waves own K quarters, lane (lr, lg) reads 32 contiguous bytes of
+// row lr per 64-deep step, 8 steps in flight.  PACKED: the same bytes per wave, but laid out so that every wave-instruction
+// reads 1 KiB contiguous and a wave's instructions walk one contiguous region (what a pre-permuted weight copy would give).
+template <bool PACKED>
+__global__ __launch_bounds__(256) void gemvlike(const short* __restrict__ B, int K, int* sink) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
+  const int per = K / 64 / 4;                       // steps per wave
+  short8_t acc = {0, 0, 0, 0, 0, 0, 0, 0};
+  const short* base = B + (size_t)blockIdx.x * 16 * K;
+  for (int s = 0; s < per; s += 8) {
+    short8_t w0[8], w1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (PACKED) {
+        const short* p = base + ((size_t)(wave * per + s + u) * 2) * 512 + lane * 8;
+        w0[u] = __builtin_nontemporal_load((const short8_t*)p);
+        w1[u] = __builtin_nontemporal_load((const short8_t*)(p + 512));
+      } else {
+        const short* p = base + (size_t)lr * K + (wave * per + s + u) * 64 + lg * 16;
+        w0[u] = __builtin_nontemporal_load((const short8_t*)p);
+        w1[u] = __builtin_nontemporal_load((const short8_t*)(p + 8));
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc ^= w0[u] ^ w1[u];
+  }
+  if (acc[0] == 12345 && acc[3] == 77) sink[0] = 1;
+}
+
 int main() {
   const int K = 4096, nsteps = K / 64, NB = 256, N = NB * 256;
   const size_t bytes = (size_t)N * K * 2;           // 512 MiB per matrix
@@ -114,5 +143,7 @@ int main() {
   time("burst<2> (2x2 steps)", [&](short* b) { hipLaunchKernelGGL(burst<2>, dim3(NB), dim3(512), 0, 0, b, K, nsteps, sink); });
   time("burst<4> (2x4 steps)", [&](short* b) { hipLaunchKernelGGL(burst<4>, dim3(NB), dim3(512), 0, 0, b, K, nsteps, sink); });
   time("burst<8> (2x8 steps)", [&](short* b) { hipLaunchKernelGGL(burst<8>, dim3(NB), dim3(512), 0, 0, b, K, nsteps, sink); });
+  time("gemv order (16 rows/WG)", [&](short* b) { hipLaunchKernelGGL(gemvlike<false>, dim3(N / 16), dim3(256), 0, 0, b, K, sink); });
+  time("gemv order, packed copy", [&](short* b) { hipLaunchKernelGGL(gemvlike<true>, dim3(N / 16), dim3(256), 0, 0, b, K, sink); });
   return 0;
 }

@@ -107,15 +107,16 @@ class GemmProbe:
             return f
 
         self.fused = set()
-        self.orig_fused = (ops.gemm_residual_rmsnorm, ops.gemm_residual_layernorm)
+        self.orig_fused = (ops.gemm_residual_rmsnorm, ops.gemm_residual_layernorm, ops.gemm_rmsnorm_bwd)
         ops.gemm = timed                     # modules call ops.* through the module attribute, so patching ops is enough
         ops.gemm_residual_rmsnorm = timed_fused(self.orig_fused[0])
         ops.gemm_residual_layernorm = timed_fused(self.orig_fused[1])
+        ops.gemm_rmsnorm_bwd = timed_fused(self.orig_fused[2])   # dgrad Linear + the norm backward that reads it
         return self
 
     def __exit__(self, *exc):
         self.ops.gemm = self.orig
-        self.ops.gemm_residual_rmsnorm, self.ops.gemm_residual_layernorm = self.orig_fused
+        self.ops.gemm_residual_rmsnorm, self.ops.gemm_residual_layernorm, self.ops.gemm_rmsnorm_bwd = self.orig_fused
 
     def summary(self):
         torch.cuda.synchronize()

@@ -53,6 +53,11 @@ int mh_gemm_residual_rmsnorm(const void* A, int lda, const void* B, int ldb, flo
 int mh_gemm_residual_layernorm(const void* A, int lda, const void* B, int ldb, float* H, int ldh, const float* bias,
                                const float* residual, int ldr, const float* norm_w, const float* norm_b, float eps, void* Y,
                                int M, int N, int K, mh_stream_t s);
+/* dY = A.B^T (a dgrad Linear) followed by the RMSNorm backward that consumes it: dx = d rmsnorm(x; w)(dY) + dres, written
+ * as f32 (dx) and/or bf16 (dx_bf16).  dy_buf: [M, N] f32 scratch (used when K is not split).  Same bits as
+ * mh_gemm_bf16_nt(..., MH_GEMM_OUT_F32) + mh_rmsnorm_bwd; one launch and one pass over dY less when K is split. */
+int mh_gemm_rmsnorm_bwd(const void* A, int lda, const void* B, int ldb, float* dy_buf, const float* x, const float* w,
+                        const float* dres, float* dx, void* dx_bf16, int M, int N, int K, float eps, mh_stream_t s);
 
 /* Scratch for the automatic split-K path of mh_gemm_bf16_nt (used for shapes whose tile count under-fills the
  * 256 CUs).  The caller owns the buffer; pass NULL to disable.  Not needed for correctness. */

@@ -653,6 +653,37 @@ extern "C" int mh_gemm_residual_layernorm(const void* A, int lda, const void* B,
   return gemm_residual_norm(1, A, lda, B, ldb, H, ldh, bias, residual, ldr, norm_w, norm_b, eps, Y, N, M, N, K, stream);
 }
 
+int mh_launch_rmsnorm_bwd(const float* dy, int nslab, long slab, long ldy, const float* x, const float* w, const float* dres,
+                          float* dx, void* dx_bf16, int M, int D, float eps, hipStream_t stream);
+
+// dY[M,N] = A.B^T (a dgrad GEMM), then the RMSNorm backward that consumes it (modeling_llama.py:66-74 under autograd):
+// dx = rmsnorm_bwd(dY, x, w) + dres.  When the policy splits K the norm kernel sums the partial slabs itself; otherwise dY
+// goes through dy_buf [M, N] f32.  Bit-identical to mh_gemm_bf16_nt followed by mh_rmsnorm_bwd.
+extern "C" int mh_gemm_rmsnorm_bwd(const void* A, int lda, const void* B, int ldb, float* dy_buf, const float* x, const float* w,
+                                   const float* dres, float* dx, void* dx_bf16, int M, int N, int K, float eps,
+                                   hipStream_t stream) {
+  if (M <= 0 || N <= 0) return MH_OK;
+  if (!dy_buf || !x || !w || (N % 4) != 0 || N > 8192) return MH_ERR_ARG;
+  int kernel = 1, splits = 1;
+  if (K > 0) gemm_plan(M, N, K, MH_GEMM_OUT_F32, &kernel, &splits);
+  if (splits > 1 && kernel != 0 && (K % 64) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 &&
+      !(((uintptr_t)A | (uintptr_t)B) & 15)) {
+    GemmArgs g = {A, lda, B, ldb, (void*)dy_buf, N, M, N, K, nullptr, nullptr, 0, MH_GEMM_OUT_F32, 1.0f, 1, K / 64, 0L};
+    if (kernel == 2) g.flags |= 12 << MH_GEMM_VARIANT_SHIFT;
+    if (kernel == 3) g.flags |= 13 << MH_GEMM_VARIANT_SHIFT;
+    const int nt = K / 64;                          // the split count run_splitk will settle on
+    int sp = splits > nt ? nt : splits;
+    const int tps = (nt + sp - 1) / sp;
+    sp = (nt + tps - 1) / tps;
+    const int rc = run_splitk(g, splits, g_ws, stream, /*reduce=*/false);
+    if (rc) return rc;
+    return mh_launch_rmsnorm_bwd(g_ws, sp, (long)M * N, N, x, w, dres, dx, dx_bf16, M, N, eps, stream);
+  }
+  const int rc = mh_gemm_bf16_nt(A, lda, B, ldb, dy_buf, N, M, N, K, nullptr, nullptr, 0, MH_GEMM_OUT_F32, 1.0f, stream);
+  if (rc) return rc;
+  return mh_launch_rmsnorm_bwd(dy_buf, 1, 0, N, x, w, dres, dx, dx_bf16, M, N, eps, stream);
+}
+
 // ---- explicit split-K entry (wgrad of the conv stem: M,N small, K huge); caller passes the scratch ----
 extern "C" long mh_gemm_splitk_ws_floats(int M, int N, int splits) { return (long)M * N * splits; }
 

@@ -197,8 +197,8 @@ class LlamaHIP:
             li = n_layers - 1 - ri
             dact = ops.gemm(dh_b, L["wdT"])                                 # [M, I] bf16
             dgu = ops.silu_mul_bwd(dact, gu)
-            dxn2 = ops.gemm(dgu, L["wguT"], out_dtype=F32)                  # [M, D]
-            dh2, dh2_b = ops.rmsnorm_bwd(dxn2, h2, L["ln2"], self.eps, dres=dh, want_bf16=True)
+            # gate|up dgrad [M, D] and the post-attention norm's backward in one call (split-K slabs summed in the norm kernel)
+            dh2, dh2_b = ops.gemm_rmsnorm_bwd(dgu, L["wguT"], h2, L["ln2"], self.eps, dres=dh)
             do = ops.gemm(dh2_b, L["woT"])                                  # [M, W] bf16
             q3 = qkv.view(B, S, 3 * W)
             dqkv = torch.empty_like(qkv)

@@ -284,6 +284,24 @@ def rmsnorm_bwd(dy, x, w, eps: float, dres=None, want_f32=True, want_bf16=False)
     return dx, dxb
 
 
+def gemm_rmsnorm_bwd(a, b, x, w, eps: float, dres=None, want_f32=True, want_bf16=True):
+    """dY = a @ b^T (f32), then rmsnorm_bwd(dY, x, w) + dres -> (dx f32, dx bf16): a dgrad Linear and the norm backward that
+    reads it, with the split-K partials summed inside the norm kernel.  Same bits as gemm(out f32) + rmsnorm_bwd."""
+    _chk2d(a, BF16, "gemm_rmsnorm_bwd.a")
+    _chk2d(b, BF16, "gemm_rmsnorm_bwd.b")
+    M, K = a.shape
+    N = b.shape[0]
+    if x.shape != (M, N) or b.shape[1] != K:
+        raise _lib.MyriadHipError(f"gemm_rmsnorm_bwd: a {tuple(a.shape)} b {tuple(b.shape)} x {tuple(x.shape)}")
+    dy = torch.empty((M, N), dtype=F32, device=a.device)
+    dx = torch.empty((M, N), dtype=F32, device=a.device) if want_f32 else None
+    dxb = torch.empty((M, N), dtype=BF16, device=a.device) if want_bf16 else None
+    rc = _L().mh_gemm_rmsnorm_bwd(_p(a), a.stride(0), _p(b), b.stride(0), _p(dy), _p(x), _p(w), _p(dres), _p(dx), _p(dxb),
+                                  M, N, K, float(eps), _s())
+    _lib.check(rc, f"mh_gemm_rmsnorm_bwd M={M} N={N} K={K}")
+    return dx, dxb
+
+
 def layernorm_fwd(x, w, b, eps: float, want_bf16=True, want_f32=False):
     M, D = x.shape
     yb = torch.empty((M, D), dtype=BF16, device=x.device) if want_bf16 else None

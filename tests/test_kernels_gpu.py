@@ -215,6 +215,28 @@ def test_gemm_residual_layernorm_is_bit_identical_to_two_launches(M, N, K):
     assert relerr(y.float(), ref) < 1e-2
 
 
+@pytest.mark.parametrize("M,N,K", [(1184, 4096, 22016), (1184, 4096, 4096), (300, 512, 256), (148, 4096, 11008), (37, 64, 128)])
+def test_gemm_rmsnorm_bwd_is_bit_identical_to_two_launches(M, N, K):
+    """A dgrad Linear and the RMSNorm backward that consumes it: the split-K slabs are summed inside the norm kernel (split
+    shapes) or the GEMM writes dY and the norm kernel reads it (the rest) -- same bits either way; and against torch autograd."""
+    ops.ensure_workspace(DEV)
+    a = bf(rnd(M, K, seed=71)).to(DEV)
+    b = bf(rnd(N, K, seed=72) * 0.05).to(DEV)
+    x = rnd(M, N, seed=73).to(DEV)
+    w = (1 + 0.1 * rnd(N, seed=74)).to(DEV)
+    dres = rnd(M, N, seed=75).to(DEV)
+    dy = ops.gemm(a, b, out_dtype=torch.float32)
+    dx_ref, dxb_ref = ops.rmsnorm_bwd(dy, x, w, 1e-6, dres=dres, want_bf16=True)
+    dx, dxb = ops.gemm_rmsnorm_bwd(a, b, x, w, 1e-6, dres=dres)
+    assert torch.equal(dx, dx_ref) and torch.equal(dxb, dxb_ref)
+    dx2, _ = ops.gemm_rmsnorm_bwd(a, b, x, w, 1e-6, want_bf16=False)
+    assert torch.equal(dx2, ops.rmsnorm_bwd(dy, x, w, 1e-6)[0])
+    xt = x.clone().requires_grad_(True)
+    y = xt * torch.rsqrt(xt.pow(2).mean(-1, keepdim=True) + 1e-6) * w
+    y.backward(a.float() @ b.float().T)
+    assert relerr(dx, xt.grad + dres) < 2e-4
+
+
 def test_gemm_rejects_bad_k():
     a = bf(rnd(8, 40)).to(DEV)
     b = bf(rnd(8, 40)).to(DEV)

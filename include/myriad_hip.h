@@ -211,6 +211,18 @@ int mh_bilinear_ac(const float* in, float* out, int B, int h, int w, int H, int 
 const char* mh_version(void);
 int mh_target_arch(void); /* 950 */
 
+/* K17 image front-end (data path, SURVEY 8 f-2 image side): what datasets/datasets/anomaly_detection.py:118-122,246 and
+ * processors/blip_processors.py:21-29,120-147,189-203 do on the CPU with torchvision + Pillow -- Resize(BICUBIC) ->
+ * CenterCrop -> ToTensor -> Normalize -- for one uint8 RGB image resident in HBM, bit-exact with Pillow's 8-bit resampler.
+ * kh/bh, kv/bv: 22-bit fixed-point weights [res][ksz] and (first, count) bounds [res][2] of the full resize per axis (device
+ * ints, built by the host exactly as Resample.c builds them); (crop_y0, crop_x0, out_h, out_w) the kept window; (y0, rows)
+ * the input rows that window taps; tmp rows*out_w*3 bytes; lut [3][256] float = ((v/255) - mean) / std in float32.
+ * out [3][out_h][out_w] f32 and/or u8_out [out_h][out_w][3] (the uint8 crop the NSA augmentation edits). */
+int mh_image_resize_crop_norm(const void* img, int H, int W, long row_stride, const int* kh, const int* bh, int ksz_h,
+                              const int* kv, const int* bv, int ksz_v, int crop_y0, int crop_x0, int out_h, int out_w, int y0,
+                              int rows, void* tmp, const float* lut, float* out, void* u8_out, mh_stream_t s);
+int mh_image_u8_normalize(const void* u8_hwc, long n_pix, const float* lut, float* out, mh_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -250,3 +250,29 @@ def expert_prompt_ids(n_obj: int, n_normal: int, n_abnormal: int, seed: int, voc
         return ids
 
     return make(n_obj * n_normal), make(n_obj * n_abnormal)
+
+
+# ---- image front-end (image side): name -> (H, W, size, mode, seed); inputs are regenerated from the seed
+IMAGE_CASES = {
+    "down3_landscape": (97, 131, 32, "train", 11),     # 3x minification, wider than tall, odd sizes
+    "down_portrait": (150, 101, 32, "train", 12),      # taller than wide
+    "upscale": (20, 27, 32, "train", 13),              # magnification (support not scaled)
+    "square_same": (32, 32, 32, "train", 14),          # nothing to resample: both passes are identities
+    "one_axis": (64, 32, 32, "train", 15),             # only the vertical axis changes size
+    "eval_aniso": (75, 121, 32, "eval", 16),           # Resize((S, S)): different scale per axis, no crop
+    "full_224": (260, 346, 224, "train", 17),          # the shipped size on a small input
+}
+
+
+def image_case(H: int, W: int, seed: int):
+    """Seeded uint8 RGB image: smooth gradients + blocks + noise, so that clipping (over/undershoot of the cubic) occurs."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = np.stack([(xx * 255 // max(W - 1, 1)), (yy * 255 // max(H - 1, 1)), ((xx + yy) * 7 % 256)], -1).astype(np.int64)
+    img += rng.integers(-40, 41, (H, W, 3))
+    blocks = rng.integers(0, 2, ((H + 7) // 8, (W + 7) // 8, 1)).repeat(8, 0).repeat(8, 1)[:H, :W]
+    img = np.where(blocks > 0, img, 255 - img)
+    hard = rng.integers(0, 256, (H, W, 3))
+    mask = rng.random((H, W, 1)) < 0.05
+    return np.clip(np.where(mask, hard, img), 0, 255).astype(np.uint8)

@@ -221,6 +221,8 @@ def main():
     ap.add_argument("--llm-layers", type=int, default=32)
     ap.add_argument("--vit-depth", type=int, default=39)
     ap.add_argument("--qf-layers", type=int, default=12)
+    ap.add_argument("--no-prefetch-vit", action="store_true",
+                    help="run the frozen ViT forward inline at the start of its own step instead of one step ahead on a side stream")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 line (BASELINE configs[1]) reported as config1_b1")
     a = ap.parse_args()
 
@@ -252,9 +254,15 @@ def main():
     samples = make_samples(a.batch, cfg["vocab"], 42 + rank, dev)
     overlap = os.environ.get("MYRIAD_NO_OVERLAP") != "1"
 
+    prefetch = not a.no_prefetch_vit
+
     def step(i, smp=samples):
-        # N>1: the gradient all-reduce (RCCL, side stream) + AdamW of step i are applied under step i+1's ViT forward
-        return model.train_step(smp, sched.step(0, i), 0.05, dp=dp if world > 1 else None, world=world, overlap=overlap)
+        # Input-pipeline lookahead of one batch (what a DataLoader with prefetch gives): every step issues the frozen ViT
+        # forward of the NEXT step's batch on a side stream, where it fills the CUs this step leaves idle; one ViT forward
+        # per step, as before.  N>1: the gradient all-reduce (RCCL, side stream) + AdamW of step i run while step i+1 waits
+        # for them with that side-stream ViT forward in flight.
+        return model.train_step(smp, sched.step(0, i), 0.05, dp=dp if world > 1 else None, world=world, overlap=overlap,
+                                next_samples=smp if prefetch else None)
 
     for i in range(a.warmup):
         step(i)

@@ -460,11 +460,23 @@ static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t str
 // caller-provided scratch for the automatic split-K path (no hidden allocation): mh_set_workspace once per device
 static float* g_ws = nullptr;
 static size_t g_ws_bytes = 0;
+static float* g_ws_alt = nullptr;
+static hipStream_t g_ws_alt_stream = nullptr;
 extern "C" int mh_set_workspace(void* ptr, long bytes) {
   g_ws = (float*)ptr;
   g_ws_bytes = ptr ? (size_t)bytes : 0;
+  if (!ptr) { g_ws_alt = nullptr; g_ws_alt_stream = nullptr; }
   return MH_OK;
 }
+// A second scratch of the same size for launches on ONE other stream (a frozen forward running beside the main stream):
+// the split-K slabs of two concurrent GEMMs must not share memory.  ptr = NULL unregisters.
+extern "C" int mh_set_stream_workspace(hipStream_t stream, void* ptr, long bytes) {
+  if (ptr && (!g_ws || (size_t)bytes < g_ws_bytes || !stream)) return MH_ERR_ARG;
+  g_ws_alt = (float*)ptr;
+  g_ws_alt_stream = ptr ? stream : nullptr;
+  return MH_OK;
+}
+static inline float* ws_for(hipStream_t stream) { return (g_ws_alt && stream == g_ws_alt_stream) ? g_ws_alt : g_ws; }
 
 int mh_launch_gemv(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                    const float* bias, const float* residual, int ldr, int out_f32, float alpha, hipStream_t stream);
@@ -585,19 +597,19 @@ extern "C" int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
       else g.flags |= 13 << MH_GEMM_VARIANT_SHIFT;
     }
     // the split-K reduce reads `residual` and writes C element-wise, so C may alias residual (in-place accumulate)
-    return splits > 1 ? run_splitk(g, splits, g_ws, stream) : dispatch(g, stream);
+    return splits > 1 ? run_splitk(g, splits, ws_for(stream), stream) : dispatch(g, stream);
   }
   // forced variants (A/B tools): the 8-wave kernels still pick their own split count
   if ((variant == 11 || variant == 12) && g_ws && (N % 4) == 0) {
     const int best = big_tile_splits(M, N, K, variant == 12 ? 256 : 128);
-    if (best > 1 && (size_t)best * M * N * sizeof(float) <= g_ws_bytes) return run_splitk(g, best, g_ws, stream);
+    if (best > 1 && (size_t)best * M * N * sizeof(float) <= g_ws_bytes) return run_splitk(g, best, ws_for(stream), stream);
   }
   if (variant == 13) {
     if (M > 288 || (N % 4) != 0 || ((uintptr_t)bias & 15) || ((uintptr_t)residual & 15)) return MH_ERR_UNSUPPORTED;
     int s = g_ws ? stream_splits(M, N, K) : 1;
     if (const char* e = getenv("MYRIAD_STREAM_SPLITS")) s = atoi(e) > 0 && g_ws ? atoi(e) : s;
     while (s > 1 && (size_t)s * M * N * sizeof(float) > g_ws_bytes) --s;
-    if (s > 1) return run_splitk(g, s, g_ws, stream);
+    if (s > 1) return run_splitk(g, s, ws_for(stream), stream);
   }
   return dispatch(g, stream);
 }
@@ -623,13 +635,14 @@ static int gemm_residual_norm(int norm, const void* A, int lda, const void* B, i
     int sp = splits > nt ? nt : splits;
     const int tps = (nt + sp - 1) / sp;
     sp = (nt + tps - 1) / tps;
-    int rc = run_splitk(g, splits, g_ws, stream, /*reduce=*/false);
+    float* wsp = ws_for(stream);
+    int rc = run_splitk(g, splits, wsp, stream, /*reduce=*/false);
     if (rc) return rc;
     if (norm == 0)
-      hipLaunchKernelGGL(splitk_reduce_norm_kernel<0>, dim3(M), dim3(256), 0, stream, g_ws, bias, residual, H, norm_w, norm_b,
+      hipLaunchKernelGGL(splitk_reduce_norm_kernel<0>, dim3(M), dim3(256), 0, stream, wsp, bias, residual, H, norm_w, norm_b,
                          (bf16_t*)Y, N, (long)ldr, (long)ldh, ldy, (long)M * N, sp, eps);
     else
-      hipLaunchKernelGGL(splitk_reduce_norm_kernel<1>, dim3(M), dim3(256), 0, stream, g_ws, bias, residual, H, norm_w, norm_b,
+      hipLaunchKernelGGL(splitk_reduce_norm_kernel<1>, dim3(M), dim3(256), 0, stream, wsp, bias, residual, H, norm_w, norm_b,
                          (bf16_t*)Y, N, (long)ldr, (long)ldh, ldy, (long)M * N, sp, eps);
     MH_CHECK_LAUNCH();
     return MH_OK;
@@ -675,9 +688,10 @@ extern "C" int mh_gemm_rmsnorm_bwd(const void* A, int lda, const void* B, int ld
     int sp = splits > nt ? nt : splits;
     const int tps = (nt + sp - 1) / sp;
     sp = (nt + tps - 1) / tps;
-    const int rc = run_splitk(g, splits, g_ws, stream, /*reduce=*/false);
+    float* wsp = ws_for(stream);
+    const int rc = run_splitk(g, splits, wsp, stream, /*reduce=*/false);
     if (rc) return rc;
-    return mh_launch_rmsnorm_bwd(g_ws, sp, (long)M * N, N, x, w, dres, dx, dx_bf16, M, N, eps, stream);
+    return mh_launch_rmsnorm_bwd(wsp, sp, (long)M * N, N, x, w, dres, dx, dx_bf16, M, N, eps, stream);
   }
   const int rc = mh_gemm_bf16_nt(A, lda, B, ldb, dy_buf, N, M, N, K, nullptr, nullptr, 0, MH_GEMM_OUT_F32, 1.0f, stream);
   if (rc) return rc;

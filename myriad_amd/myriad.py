@@ -21,7 +21,7 @@ from typing import Dict, List, Optional, Tuple
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import _lib, ops
 from .eva_vit import EvaViTHIP
 from .llama import LlamaHIP
 from .networks import LoraAdaptor, VENet, from_reference_layout, to_reference_layout, ve_param_specs
@@ -173,6 +173,7 @@ class MyriadHIP(nn.Module):
                                self.store.p, self.store.g, self._dev)
             self.llama.attach_lora(self.lora)
         self._pending_update = None
+        self._vit_stream, self._vit_ws, self._vit_prefetched = None, None, None
         self._anchor = torch.zeros((), device=self._dev, requires_grad=True)
         self._ctx = None
 
@@ -430,16 +431,48 @@ class MyriadHIP(nn.Module):
             if prm.grad is None or prm.grad.data_ptr() != self.store.g[name].data_ptr():
                 prm.grad = self.store.g[name]
 
+    def prefetch_vit(self, samples) -> None:
+        """Launch the frozen ViT forward of a LATER step on a side stream, so that it fills the CUs the current step leaves
+        idle (partial tile rounds, launch gaps, latency-bound small kernels).  The result is picked up by the train_step()
+        that receives the same `samples` object.  Its split-K GEMMs use their own scratch (mh_set_stream_workspace)."""
+        if self._vit_stream is None:
+            self._vit_stream = torch.cuda.Stream(device=self._dev)
+            ws = ops.ensure_workspace(self._dev)
+            self._vit_ws = torch.empty(ws.numel(), dtype=torch.uint8, device=self._dev)
+            _lib.check(_lib.load().mh_set_stream_workspace(self._vit_stream.cuda_stream, self._vit_ws.data_ptr(),
+                                                           self._vit_ws.numel()), "mh_set_stream_workspace")
+        main = torch.cuda.current_stream()
+        self._vit_stream.wait_stream(main)               # inputs uploaded / buffers freed on the main stream so far
+        with torch.cuda.stream(self._vit_stream), torch.no_grad():
+            out = self.visual_encoder.forward(self._image_of(samples))
+            ev = torch.cuda.Event()
+            ev.record()
+        self._vit_prefetched = (samples, out, ev)
+
+    def _take_prefetched_vit(self, samples):
+        if self._vit_prefetched is None or self._vit_prefetched[0] is not samples:
+            return None
+        _, out, ev = self._vit_prefetched
+        self._vit_prefetched = None
+        main = torch.cuda.current_stream()
+        main.wait_event(ev)
+        out.record_stream(main)                          # allocated on the side stream, consumed (and freed) on this one
+        return out
+
     def train_step(self, samples, lr: float, weight_decay: float = 0.05, allreduce=None, world: int = 1, dp=None,
-                   overlap: bool = True):
+                   overlap: bool = True, next_samples=None):
         """forward + backward (+ gradient all-reduce) + fused AdamW: one optimisation step of
         `BaseTask._train_inner_loop` (base_task.py:233-271) without the autograd bridge.
         With a `DataParallel` (`dp`) and overlap=True the all-reduce + AdamW of step t are hidden behind the frozen
         ViT forward of step t+1 (95 % of the gradient bytes only exist after the whole LLaMA backward, so
         overlapping with backward hides nothing); call `finish_update()` after the last step."""
         with torch.no_grad():
-            vit_out = None
-            if self._pending_update is not None:
+            vit_out = self._take_prefetched_vit(samples)
+            if next_samples is not None:
+                self.prefetch_vit(next_samples)         # runs beside everything below
+            if self._pending_update is not None and vit_out is not None:
+                self.finish_update()
+            elif self._pending_update is not None:
                 # The previous step's gradient all-reduce is still in flight on the side stream: run this step's
                 # frozen ViT forward (independent of the update) under it, then apply the delayed AdamW.
                 vit_out = self.visual_encoder.forward(self._image_of(samples))

@@ -127,17 +127,20 @@ def init_distributed(backend: Optional[str] = None):
 
 def train_loop(model, data_iter: Callable[[], dict], n_steps: int, scheduler: LinearWarmupCosineLRScheduler,
                weight_decay: float = 0.05, dp: Optional[DataParallel] = None, epoch: int = 0,
-               log: Optional[Callable[[int, float, float], None]] = None):
+               log: Optional[Callable[[int, float, float], None]] = None, lookahead: bool = True):
     """`BaseTask._train_inner_loop` for the HIP model: lr is stepped BEFORE the forward with (epoch, i)
     (base_task.py:229), then forward/backward/all-reduce/AdamW."""
     world = dp.world if dp is not None else 1
     losses = []
+    samples = data_iter() if n_steps > 0 else None
     for i in range(n_steps):
         lr = scheduler.step(cur_epoch=epoch, cur_step=i)
-        samples = data_iter()
-        loss = model.train_step(samples, lr, weight_decay, dp=(dp if dp and world > 1 else None), world=world)
+        nxt = data_iter() if (i + 1 < n_steps and lookahead) else None     # one batch ahead: its frozen ViT forward is
+        loss = model.train_step(samples, lr, weight_decay, dp=(dp if dp and world > 1 else None), world=world,
+                                next_samples=nxt)                           # issued beside this step (side stream)
         losses.append(loss)
         if log is not None:
             log(i, float(loss), lr)      # device->host sync per step like metric_logger.update(loss.item())
+        samples = nxt if nxt is not None else (data_iter() if i + 1 < n_steps else None)
     model.finish_update()                # flush the delayed (overlapped) optimiser update of the last step
     return losses

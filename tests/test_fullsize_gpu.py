@@ -105,3 +105,32 @@ def test_graph_replayed_decode_equals_eager_decode(model):
         assert torch.equal(a[:, :1], c)                              # first token = arg-max of the prefill logits
     finally:
         model.train()
+
+
+def test_vit_prefetch_on_a_side_stream_changes_nothing(model):
+    """train_step(next_samples=...) issues the NEXT batch's frozen ViT forward on a side stream (its own split-K scratch)
+    while this step runs: three optimisation steps over three different batches must leave bit-identical losses, parameters
+    and AdamW moments compared with the inline order."""
+    st = model.store
+    keep = (st.flat_p.clone(), st.flat_m.clone(), st.flat_v.clone(), st.step)
+    batches = [samples(2, seed=31 + i) for i in range(3)]
+
+    def run(lookahead):
+        st.flat_p.copy_(keep[0]); st.flat_m.copy_(keep[1]); st.flat_v.copy_(keep[2]); st.step = keep[3]
+        losses = []
+        for i, b in enumerate(batches):
+            nxt = batches[i + 1] if (lookahead and i + 1 < len(batches)) else None
+            losses.append(float(model.train_step(b, 1e-3, 0.05, next_samples=nxt)))
+        torch.cuda.synchronize()
+        return losses, st.flat_p.clone(), st.flat_m.clone(), st.flat_v.clone()
+
+    try:
+        a = run(False)
+        b = run(True)
+        assert model._vit_stream is not None                     # the side stream was really used
+        assert a[0] == b[0]
+        assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+        assert not torch.equal(a[1], keep[0])                    # and the steps did move the parameters
+    finally:
+        st.flat_p.copy_(keep[0]); st.flat_m.copy_(keep[1]); st.flat_v.copy_(keep[2]); st.step = keep[3]
+        model._vit_prefetched = None

@@ -156,7 +156,7 @@ def cpu_baseline(arch: str, stage: int, cfg: dict, budget_note: str = "") -> dic
     from tests import golden_utils as gu
     torch.manual_seed(0)
     nth = torch.get_num_threads()
-    kv, kq, kl = 2, 2, 1
+    kv, kq, kl = 8, 6, 8          # ~10 s of host work on 128 threads; deeper samples only move the extrapolation by percents
     V = 2048
     sd = {}
     sd.update(gu.vit_weights(cfg["vit_dim"], kv, cfg["vit_heads"], cfg["vit_hidden"], cfg["patch"], 257, seed=1))

@@ -283,7 +283,9 @@ int mh_launch_gemm_256(const void* A, int lda, const void* B, int ldb, void* C, 
 
 int mh_launch_gemm_stream(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                           const float* bias, const float* residual, int ldr, int flags, float alpha, int splits,
-                          int steps_per_split, long split_stride, hipStream_t stream);
+                          int steps_per_split, long split_stride, int nfb, hipStream_t stream);
+void mh_gemm_stream_plan(int M, int N, int K, int can_split, int* nfb, int* splits);
+static int stream_nfb(int M, int N, int K);
 
 static int dispatch(const GemmArgs& g, hipStream_t stream) {
   int variant = (g.flags >> MH_GEMM_VARIANT_SHIFT) & 15;
@@ -308,7 +310,7 @@ static int dispatch(const GemmArgs& g, hipStream_t stream) {
                                 g.alpha, g.splits, g.tps, g.split_stride, stream);
     case 13:                                                      // mid-M weight streaming (gemm_stream.hip)
       return mh_launch_gemm_stream(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, g.bias, g.residual, g.ldr, g.flags,
-                                   g.alpha, g.splits, g.tps, g.split_stride, stream);
+                                   g.alpha, g.splits, g.tps, g.split_stride, stream_nfb(g.M, g.N, g.K), stream);
     default: return MH_ERR_ARG;
   }
 }
@@ -444,7 +446,7 @@ static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t str
                            g.splits, g.tps, g.split_stride, stream);
   else if (((g0.flags >> MH_GEMM_VARIANT_SHIFT) & 15) == 13)
     rc = mh_launch_gemm_stream(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, nullptr, nullptr, 0, g.flags, 1.0f,
-                               g.splits, g.tps, g.split_stride, stream);
+                               g.splits, g.tps, g.split_stride, stream_nfb(g.M, g.N, g.K), stream);
   else
     rc = launch_gemm<0, 2, 128, 2>(g, stream);
   if (rc) return rc;
@@ -517,15 +519,17 @@ static int big_tile_splits(int M, int N, int K, int tile_n) {
   return best;
 }
 
-// mid-M streaming kernel: one 8-wave workgroup per 256 weight rows and K slice, one workgroup per CU (its activation ring
-// takes 96-120 KiB of LDS): as many K slices as fit one round of 256 workgroups, at least 4 steps of 64 each
+// mid-M streaming kernel (gemm_stream.hip): fragments per workgroup and K slices come from its own planner
 static int stream_splits(int M, int N, int K) {
-  (void)M;
-  const int blocks_n = (N + 255) / 256, steps = K / 64;
-  int s = 256 / blocks_n;
-  s = s < 1 ? 1 : (s > 16 ? 16 : s);
-  while (s > 1 && steps / s < 4) --s;
+  int nfb, s;
+  mh_gemm_stream_plan(M, N, K, 1, &nfb, &s);
   return s;
+}
+
+static int stream_nfb(int M, int N, int K) {
+  int nfb, s;
+  mh_gemm_stream_plan(M, N, K, g_ws && (N % 4) == 0, &nfb, &s);
+  return nfb;
 }
 
 static int stream_enabled() {

@@ -30,7 +30,7 @@ struct AttnParams {
   bf16_t* dk;
   bf16_t* dv;
   float* lse;          // [B,H,Sq]
-  const float* delta;  // [B,H,Sq] (bwd)
+  float* delta;        // [B,H,Sq] (bwd): written by the dQ kernel, read by the dK|dV kernel
   const float* bias;   // optional additive [H,Sq,Sk] fp32
   const int* kv_len;   // optional [B] valid key count (right padding)
   int B, H, Sq, Sk, D;
@@ -220,28 +220,6 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   }
 }
 
-// ------------------------------------------------------------------------------------------- delta
-// delta[b,h,q] = sum_d dO[b,q,h,d] * O[b,q,h,d]
-__global__ void attn_delta_kernel(const bf16_t* __restrict__ o, const bf16_t* __restrict__ dout, float* __restrict__ delta,
-                                  int B, int H, int Sq, int D, long o_bs, int ldo, long do_bs, int lddo) {
-  const long total = (long)B * H * Sq;
-  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
-    const int q = (int)(it % Sq);
-    const int h = (int)((it / Sq) % H);
-    const int b = (int)(it / ((long)Sq * H));
-    const bf16_t* po = o + b * o_bs + (long)q * ldo + h * D;
-    const bf16_t* pd = dout + b * do_bs + (long)q * lddo + h * D;
-    float s = 0.f;
-    for (int d = 0; d < D; d += 8) {
-      const short8_t a = *reinterpret_cast<const short8_t*>(po + d);
-      const short8_t g = *reinterpret_cast<const short8_t*>(pd + d);
-#pragma unroll
-      for (int e = 0; e < 8; ++e) s += bf2f((bf16_t)a[e]) * bf2f((bf16_t)g[e]);
-    }
-    delta[it] = s;
-  }
-}
-
 // ------------------------------------------------------------------------------------------- dQ
 template <int DP>
 __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
@@ -269,7 +247,21 @@ __global__ __launch_bounds__(256) void attn_bwd_dq_kernel(AttnParams p) {
   load_row_frags<DP>(gf, gb, p.lddo, qi, p.Sq, p.D, lg);
   const long sidx = ((long)b * p.H + h) * p.Sq + qi;
   const float lse = qi < p.Sq ? p.lse[sidx] : 0.f;
-  const float dlt = qi < p.Sq ? p.delta[sidx] : 0.f;
+  // delta[b,h,q] = sum_d dO * O for this lane's row: the four lanes of a row (lg = 0..3) hold disjoint column groups of dO
+  // already; the same groups of O are read here and the partial sums combined across the lanes.  Written out for the
+  // dK|dV kernel, which runs next on the stream (this replaces a separate delta launch per attention backward).
+  float dlt = 0.f;
+  {
+    short8_t of[DP / 32];
+    load_row_frags<DP>(of, p.o + b * p.o_bs + h * p.D, p.ldo, qi, p.Sq, p.D, lg);
+#pragma unroll
+    for (int kk = 0; kk < DP / 32; ++kk)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) dlt += bf2f((bf16_t)of[kk][e]) * bf2f((bf16_t)gf[kk][e]);
+    dlt += __shfl_xor(dlt, 16);
+    dlt += __shfl_xor(dlt, 32);
+    if (lg == 0 && qi < p.Sq) p.delta[sidx] = dlt;
+  }
 
   float4_t acc[DP / 16];
 #pragma unroll
@@ -620,12 +612,7 @@ extern "C" int mh_attn_bwd(const void* q, const void* k, const void* v, const vo
   int rc = check_common(p);
   if (rc) return rc;
   if (lddo % 8 || ldo % 8 || lddq % 4 || lddk % 4 || lddv % 4) return MH_ERR_ARG;
-  const long n = (long)B * H * Sq;
-  int g = (int)((n + 255) / 256);
-  if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(attn_delta_kernel, dim3(g), dim3(256), 0, stream, (const bf16_t*)o, (const bf16_t*)dout, delta_ws, B,
-                     H, Sq, D, o_bs, ldo, do_bs, lddo);
-  MH_CHECK_LAUNCH();
+  p.o = (bf16_t*)const_cast<void*>(o);                // read-only here: the dQ kernel derives delta from it
   if (D <= 64) return launch_bwd<64>(p, stream);
   if (D <= 96) return launch_bwd<96>(p, stream);
   return launch_bwd<128>(p, stream);

@@ -151,3 +151,44 @@ def test_gemm_policy_for_the_steps_shapes():
         assert lib.mh_gemm_plan(0, 8, 64, 0, ctypes.addressof(kernel), ctypes.addressof(splits)) != 0   # bad dims rejected
     finally:
         lib.mh_set_workspace(None, 0)
+
+
+def test_train_loop_looks_one_batch_ahead():
+    """runner.train_loop hands train_step the CURRENT batch and, as `next_samples`, the batch of the following step (whose
+    frozen ViT forward the model issues on a side stream); the iterator is advanced exactly once per step, in order, the
+    lr is stepped before each step (base_task.py:229) and the delayed update is flushed at the end."""
+    from myriad_amd.runner import LinearWarmupCosineLRScheduler, train_loop
+
+    class Recorder:
+        def __init__(self):
+            self.calls, self.flushed = [], 0
+
+        def train_step(self, samples, lr, weight_decay, dp=None, world=1, next_samples=None):
+            self.calls.append((samples["id"], None if next_samples is None else next_samples["id"], lr, weight_decay))
+            return torch.tensor(float(samples["id"]))
+
+        def finish_update(self):
+            self.flushed += 1
+
+    drawn = []
+
+    def data_iter():
+        drawn.append(len(drawn))
+        return {"id": drawn[-1]}
+
+    sched = LinearWarmupCosineLRScheduler(None, max_epoch=10, iters_per_epoch=1600, min_lr=0.0, init_lr=1e-4, warmup_steps=0,
+                                          warmup_start_lr=1e-6)
+    m = Recorder()
+    logged = []
+    losses = train_loop(m, data_iter, 4, sched, weight_decay=0.05, log=lambda i, l, lr: logged.append((i, l)))
+    assert drawn == [0, 1, 2, 3]                                          # one draw per step, no extra batch consumed
+    assert [(c[0], c[1]) for c in m.calls] == [(0, 1), (1, 2), (2, 3), (3, None)]
+    assert [float(x) for x in losses] == [0.0, 1.0, 2.0, 3.0] and logged == [(0, 0.0), (1, 1.0), (2, 2.0), (3, 3.0)]
+    assert all(c[3] == 0.05 for c in m.calls) and m.calls[0][2] == pytest.approx(1e-4)
+    assert m.flushed == 1
+    # without lookahead every step gets next_samples=None and the same batches
+    drawn.clear()
+    m2 = Recorder()
+    train_loop(m2, data_iter, 3, sched, lookahead=False)
+    assert drawn == [0, 1, 2] and [(c[0], c[1]) for c in m2.calls] == [(0, None), (1, None), (2, None)]
+    assert train_loop(Recorder(), data_iter, 0, sched) == []

@@ -62,6 +62,7 @@ class LoraQV:
         self.step_seed = 0
         self._xext: Dict[Tuple[int, int], torch.Tensor] = {}
         self._ws = torch.empty((_lib.load().mh_lora_wgrad_ws_floats(D, 2 * r),), dtype=F32, device=self.dev)
+        self._deferred, self._side, self._wgrad_ev = [], None, None
 
     def names(self, i):
         p = f"{PEFT_PREFIX}{i}.self_attn."
@@ -122,21 +123,56 @@ class LoraQV:
 
     # ---- backward ------------------------------------------------------------------------------------------------
     def backward(self, layer_idx: int, dx_ext: torch.Tensor, dqkv: torch.Tensor, x_ext: torch.Tensor, p: float,
-                 seed: int) -> torch.Tensor:
+                 seed: int, defer_wgrad: bool = False) -> torch.Tensor:
         """dx_ext [M, D+64] f32 = dqkv . [W | B_ext];  returns the full d(xn) [M, D] f32 (contiguous) and writes
-        dA_q, dA_v, dB_q, dB_v into the flat gradient buffer."""
+        dA_q, dA_v, dB_q, dB_v into the flat gradient buffer.  The weight gradients feed nothing but the optimiser, so with
+        defer_wgrad they are only queued: run_deferred_wgrads() launches them on a side stream beside whatever the caller
+        does next (the Q-Former / adapter backward) and join_wgrads() makes the current stream wait for them."""
+        if defer_wgrad:
+            self._deferred.append((layer_idx, dx_ext, dqkv, x_ext, p, seed))
+        else:
+            self._wgrad(layer_idx, dx_ext, dqkv, x_ext, p, seed)
+        D, r = self.D, self.r
+        M = dx_ext.shape[0]
+        A = self._aqv(self.P, layer_idx)
+        dxn = torch.empty((M, D), dtype=F32, device=self.dev)
+        _lib.check(_lib.load().mh_lora_dx(dx_ext.data_ptr(), dx_ext.stride(0), A.data_ptr(), dxn.data_ptr(), M, D, 2 * r, self.s,
+                                          p, seed, ops._s()), "mh_lora_dx")
+        return dxn
+
+    def _wgrad(self, layer_idx, dx_ext, dqkv, x_ext, p, seed) -> None:
         D, r, W = self.D, self.r, self.D
         M = dx_ext.shape[0]
         _, _, nb_q, nb_v = self.names(layer_idx)
-        L = _lib.load()
-        A = self._aqv(self.P, layer_idx)
         gA = self._aqv(self.G, layer_idx)
         dv = dqkv[:, 2 * W:]
-        _lib.check(L.mh_lora_wgrad(x_ext.data_ptr(), x_ext.stride(0), dx_ext.data_ptr(), dx_ext.stride(0),
-                                   dqkv.data_ptr(), dv.data_ptr(), dqkv.stride(0), x_ext[:, D:].data_ptr(),
-                                   x_ext.stride(0), gA.data_ptr(), self.G[nb_q].data_ptr(), self.G[nb_v].data_ptr(),
-                                   self._ws.data_ptr(), M, D, 2 * r, self.s, p, seed, ops._s()), "mh_lora_wgrad")
-        dxn = torch.empty((M, D), dtype=F32, device=self.dev)
-        _lib.check(L.mh_lora_dx(dx_ext.data_ptr(), dx_ext.stride(0), A.data_ptr(), dxn.data_ptr(), M, D, 2 * r, self.s, p,
-                                seed, ops._s()), "mh_lora_dx")
-        return dxn
+        _lib.check(_lib.load().mh_lora_wgrad(x_ext.data_ptr(), x_ext.stride(0), dx_ext.data_ptr(), dx_ext.stride(0),
+                                             dqkv.data_ptr(), dv.data_ptr(), dqkv.stride(0), x_ext[:, D:].data_ptr(),
+                                             x_ext.stride(0), gA.data_ptr(), self.G[nb_q].data_ptr(), self.G[nb_v].data_ptr(),
+                                             self._ws.data_ptr(), M, D, 2 * r, self.s, p, seed, ops._s()), "mh_lora_wgrad")
+
+    def run_deferred_wgrads(self) -> None:
+        """Launch the queued weight gradients on the side stream (ordered after everything the current stream has queued)."""
+        if not self._deferred:
+            return
+        if self._side is None:
+            self._side = torch.cuda.Stream(device=self.dev)
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side):
+            for (li, dx_ext, dqkv, x_ext, p, seed) in self._deferred:
+                for t in (dx_ext, dqkv):
+                    t.record_stream(self._side)          # allocated on the main stream, read here
+                self._wgrad(li, dx_ext, dqkv, x_ext, p, seed)
+            self._wgrad_ev = torch.cuda.Event()
+            self._wgrad_ev.record()
+        self._deferred = []
+
+    def join_wgrads(self) -> None:
+        if self._deferred:                               # never launched: run them here, in order
+            for item in self._deferred:
+                self._wgrad(*item)
+            self._deferred = []
+        if self._wgrad_ev is not None:
+            torch.cuda.current_stream().wait_event(self._wgrad_ev)
+            self._wgrad_ev = None

@@ -392,7 +392,7 @@ class MyriadHIP(nn.Module):
         if gscale != 1.0:
             raise NotImplementedError("bf16 path needs no loss scaling")
         self.store.flat_g.zero_()
-        demb = self.llama.backward()                                  # [B,S,Dl] f32
+        demb = self.llama.backward(defer_lora_join=True)              # [B,S,Dl] f32; LoRA wgrads run on a side stream
         B, nq = c["B"], c["nq"]
         (c0, n0) = c["img_slices"][0]
         dimg = torch.empty((B, nq, self.Dl), dtype=F32, device=self._dev)
@@ -403,6 +403,8 @@ class MyriadHIP(nn.Module):
             ops.gemm_auto_f32(ops.transpose_to_bf16(dimg_b, 64), ops.transpose_to_bf16(c["qo_b"], 64),
                               self.store.g["llama_proj.weight"])
             self.store.g["llama_proj.bias"].copy_(ops.colsum(dimg.view(B * nq, self.Dl)))
+            if self.llama.lora is not None:
+                self.llama.lora.join_wgrads()
             self._reattach_grads()
             self._ctx = None
             return
@@ -422,6 +424,8 @@ class MyriadHIP(nn.Module):
             self.ve_ins.backward(dins)
         dy, _ = ops.layernorm_bwd(denc.view(B * c["N"], self.Dv), c["y"], self.ln_w, 1e-5)
         self.adaptor.backward(dy)
+        if self.llama.lora is not None:
+            self.llama.lora.join_wgrads()                 # the side-stream LoRA weight gradients land before anyone reads flat_g
         self._reattach_grads()
         self._ctx = None
 

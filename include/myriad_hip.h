@@ -62,8 +62,8 @@ int mh_gemm_rmsnorm_bwd(const void* A, int lda, const void* B, int ldb, float* d
 /* Scratch for the automatic split-K path of mh_gemm_bf16_nt (used for shapes whose tile count under-fills the
  * 256 CUs).  The caller owns the buffer; pass NULL to disable.  Not needed for correctness. */
 int mh_set_workspace(void* ptr, long bytes);
-/* A second scratch (>= the first one's size) for launches on ONE other stream, so that a frozen forward can run beside the
- * main stream without sharing split-K slabs with it.  ptr = NULL unregisters. */
+/* Further scratches (each >= the first one's size) for launches on other streams (up to 4), so that a frozen forward or a
+ * leaf backward can run beside the main stream without sharing split-K slabs with it.  ptr = NULL unregisters. */
 int mh_set_stream_workspace(mh_stream_t stream, void* ptr, long bytes);
 /* split-K variant (f32 out, no epilogue) for skinny outputs with a long reduction (conv-stem wgrad):
  * ws holds mh_gemm_splitk_ws_floats(M,N,splits) floats; fixed-order reduction -> deterministic. */

@@ -462,23 +462,36 @@ static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t str
 // caller-provided scratch for the automatic split-K path (no hidden allocation): mh_set_workspace once per device
 static float* g_ws = nullptr;
 static size_t g_ws_bytes = 0;
-static float* g_ws_alt = nullptr;
-static hipStream_t g_ws_alt_stream = nullptr;
+#define MH_MAX_ALT_WS 4
+static float* g_ws_alt[MH_MAX_ALT_WS] = {nullptr, nullptr, nullptr, nullptr};
+static hipStream_t g_ws_alt_stream[MH_MAX_ALT_WS] = {nullptr, nullptr, nullptr, nullptr};
 extern "C" int mh_set_workspace(void* ptr, long bytes) {
   g_ws = (float*)ptr;
   g_ws_bytes = ptr ? (size_t)bytes : 0;
-  if (!ptr) { g_ws_alt = nullptr; g_ws_alt_stream = nullptr; }
+  if (!ptr)
+    for (int i = 0; i < MH_MAX_ALT_WS; ++i) { g_ws_alt[i] = nullptr; g_ws_alt_stream[i] = nullptr; }
   return MH_OK;
 }
-// A second scratch of the same size for launches on ONE other stream (a frozen forward running beside the main stream):
-// the split-K slabs of two concurrent GEMMs must not share memory.  ptr = NULL unregisters.
+// Further scratches of the same size for launches on other streams (a frozen forward, a leaf backward running beside the
+// main stream): the split-K slabs of concurrent GEMMs must not share memory.  Up to 4 streams; ptr = NULL unregisters.
 extern "C" int mh_set_stream_workspace(hipStream_t stream, void* ptr, long bytes) {
-  if (ptr && (!g_ws || (size_t)bytes < g_ws_bytes || !stream)) return MH_ERR_ARG;
-  g_ws_alt = (float*)ptr;
-  g_ws_alt_stream = ptr ? stream : nullptr;
+  if (!stream || (ptr && (!g_ws || (size_t)bytes < g_ws_bytes))) return MH_ERR_ARG;
+  int slot = -1;
+  for (int i = 0; i < MH_MAX_ALT_WS; ++i)
+    if (g_ws_alt_stream[i] == stream) slot = i;
+  if (slot < 0)
+    for (int i = MH_MAX_ALT_WS - 1; i >= 0; --i)
+      if (!g_ws_alt_stream[i]) slot = i;
+  if (slot < 0) return ptr ? MH_ERR_UNSUPPORTED : MH_OK;
+  g_ws_alt[slot] = (float*)ptr;
+  g_ws_alt_stream[slot] = ptr ? stream : nullptr;
   return MH_OK;
 }
-static inline float* ws_for(hipStream_t stream) { return (g_ws_alt && stream == g_ws_alt_stream) ? g_ws_alt : g_ws; }
+static inline float* ws_for(hipStream_t stream) {
+  for (int i = 0; i < MH_MAX_ALT_WS; ++i)
+    if (g_ws_alt_stream[i] == stream && g_ws_alt[i]) return g_ws_alt[i];
+  return g_ws;
+}
 
 int mh_launch_gemv(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                    const float* bias, const float* residual, int ldr, int out_f32, float alpha, hipStream_t stream);

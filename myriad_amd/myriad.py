@@ -14,6 +14,7 @@ Out of scope here: the ImageBind vision expert.  Its out
 """
 from __future__ import annotations
 
+import os
 import random
 from collections import OrderedDict
 from typing import Dict, List, Optional, Tuple
@@ -173,7 +174,8 @@ class MyriadHIP(nn.Module):
                                self.store.p, self.store.g, self._dev)
             self.llama.attach_lora(self.lora)
         self._pending_update = None
-        self._vit_stream, self._vit_ws, self._vit_prefetched = None, None, None
+        self._vit_stream, self._vit_prefetched = None, None
+        self._leaf_aside = os.environ.get("MYRIAD_LEAF_STREAM", "1") != "0"
         self._anchor = torch.zeros((), device=self._dev, requires_grad=True)
         self._ctx = None
 
@@ -416,7 +418,17 @@ class MyriadHIP(nn.Module):
             self.store.g["VETokenizer.base_prompts"].view(-1).copy_(ops.colsum(dbase.view(B, 9 * self.Dl)))
             dtok = torch.empty((B, 9, self.Dl), dtype=F32, device=self._dev)
             ops.copy3d(demb[:, ct:ct + 9], dtok)
-            self.ve_tok.backward(dtok)
+            # the tokenizer's conv stack is a leaf (its input is the anomaly map): its backward feeds only the optimiser and
+            # runs on a side stream beside the Q-Former backward
+            aux, main = (self._side_stream("leaf") if self._leaf_aside else torch.cuda.current_stream()), torch.cuda.current_stream()
+            aux.wait_stream(main)
+            leaf_keep = (dtok, self.ve_tok._saved)       # main-stream allocations the side stream reads: alive until the join
+            with torch.cuda.stream(aux):
+                self.ve_tok.backward(dtok)
+                leaf_ev = torch.cuda.Event()
+                leaf_ev.record()
+        else:
+            leaf_ev, leaf_keep = None, None
         dq, denc = self.qformer.backward(dqo)
         if c["use_ins"]:
             dins = torch.empty((B, 49, self.Dq), dtype=F32, device=self._dev)
@@ -426,6 +438,9 @@ class MyriadHIP(nn.Module):
         self.adaptor.backward(dy)
         if self.llama.lora is not None:
             self.llama.lora.join_wgrads()                 # the side-stream LoRA weight gradients land before anyone reads flat_g
+        if leaf_ev is not None:
+            torch.cuda.current_stream().wait_event(leaf_ev)
+        del leaf_keep                                     # freed only now: later main-stream work is ordered behind the event
         self._reattach_grads()
         self._ctx = None
 
@@ -435,16 +450,15 @@ class MyriadHIP(nn.Module):
             if prm.grad is None or prm.grad.data_ptr() != self.store.g[name].data_ptr():
                 prm.grad = self.store.g[name]
 
+    def _side_stream(self, name: str):
+        return ops.side_stream(self._dev, name)
+
     def prefetch_vit(self, samples) -> None:
         """Launch the frozen ViT forward of a LATER step on a side stream, so that it fills the CUs the current step leaves
         idle (partial tile rounds, launch gaps, latency-bound small kernels).  The result is picked up by the train_step()
         that receives the same `samples` object.  Its split-K GEMMs use their own scratch (mh_set_stream_workspace)."""
         if self._vit_stream is None:
-            self._vit_stream = torch.cuda.Stream(device=self._dev)
-            ws = ops.ensure_workspace(self._dev)
-            self._vit_ws = torch.empty(ws.numel(), dtype=torch.uint8, device=self._dev)
-            _lib.check(_lib.load().mh_set_stream_workspace(self._vit_stream.cuda_stream, self._vit_ws.data_ptr(),
-                                                           self._vit_ws.numel()), "mh_set_stream_workspace")
+            self._vit_stream = self._side_stream("vit")
         main = torch.cuda.current_stream()
         self._vit_stream.wait_stream(main)               # inputs uploaded / buffers freed on the main stream so far
         with torch.cuda.stream(self._vit_stream), torch.no_grad():

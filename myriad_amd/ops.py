@@ -97,11 +97,28 @@ def ensure_workspace(device, nbytes: int = 256 << 20):
     return _WS[key]
 
 
+_SIDE = {}
+
+
+def side_stream(device, name: str) -> "torch.cuda.Stream":
+    """A named side stream of the device with its OWN split-K scratch (two streams that both split K must not share one;
+    mh_set_stream_workspace).  One per (device, name) for the whole process: every model instance shares them."""
+    key = (str(device), name)
+    if key not in _SIDE:
+        main_ws = ensure_workspace(device)
+        st = torch.cuda.Stream(device=device)
+        ws = torch.empty(main_ws.numel(), dtype=torch.uint8, device=device)
+        _lib.check(_L().mh_set_stream_workspace(st.cuda_stream, ws.data_ptr(), ws.numel()), "mh_set_stream_workspace")
+        _SIDE[key] = (st, ws)
+    return _SIDE[key][0]
+
+
 def drop_workspace():
     """Unregister the split-K scratch (tests: the no-workspace paths).  ensure_workspace() registers it again."""
     torch.cuda.synchronize()
-    _lib.check(_L().mh_set_workspace(None, 0), "mh_set_workspace")
+    _lib.check(_L().mh_set_workspace(None, 0), "mh_set_workspace")     # also drops every side-stream scratch
     _WS.clear()
+    _SIDE.clear()
 
 
 def round_up(x: int, m: int) -> int:

@@ -85,6 +85,25 @@ int mh_attn_bwd(const void* q, const void* k, const void* v, const void* o, cons
                 long v_bs, int ldv, long o_bs, int ldo, long do_bs, int lddo, long dq_bs, int lddq, long dk_bs,
                 int lddk, long dv_bs, int lddv, float scale, int causal, mh_stream_t s);
 
+/* K5 + K8 fused, training path: LLaMA causal self-attention with the rotary embedding applied on load
+   (modeling_llama.py:109-123 apply_rotary_pos_emb, :168-231 LlamaAttention.forward).  qkv = [q | k | v] [B, S, ld] bf16,
+   PRE-rotary, head h at columns h*D..; one workgroup per (batch, head) holds the whole sequence (S <= 160, D = 128:
+   mh_attn_rope_supported; otherwise MH_ERR_UNSUPPORTED and the caller uses mh_rope_inplace + mh_attn_fwd/bwd).
+   pos [B*S] position ids, cos/sin [max_pos, D/2] f32, kv_len optional [B] (right padding).  bwd writes
+   dqkv = [dq | dk | dv] with dq, dk already un-rotated.  mh_gemm_attn_rope_bwd = the o_proj dgrad GEMM
+   dO = A[M,K].Bw[N,K]^T followed by that backward, with the split-K partial sums of dO added up inside the attention
+   kernel (do_buf [M, N] bf16 is scratch for the unsplit case). */
+int mh_attn_rope_supported(int S, int D);
+int mh_attn_rope_fwd(const void* qkv, int ld, void* o, int ldo, float* lse, const int* pos, const float* cos_tab,
+                     const float* sin_tab, const int* kv_len, int B, int H, int S, int D, float scale, mh_stream_t s);
+int mh_attn_rope_bwd(const void* qkv, int ld, const void* o, int ldo, const void* dout, int ldd, const float* lse,
+                     void* dqkv, const int* pos, const float* cos_tab, const float* sin_tab, const int* kv_len,
+                     int B, int H, int S, int D, float scale, mh_stream_t s);
+int mh_gemm_attn_rope_bwd(const void* A, int lda, const void* Bw, int ldb, void* do_buf, int K, const void* qkv,
+                          int ld, const void* o, int ldo, const float* lse, void* dqkv, const int* pos,
+                          const float* cos_tab, const float* sin_tab, const int* kv_len, int B, int H, int S,
+                          int D, float scale, mh_stream_t s);
+
 /* K7 RMSNorm (modeling_llama.py:66-74) f32 in -> bf16 out; bwd is dgrad-only (+ optional residual-grad add,
  * optional bf16 copy of dx for the next dgrad GEMM). */
 int mh_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, long ldy, int M, int D, float eps, mh_stream_t s);

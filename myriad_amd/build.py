@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libmyriad_hip.so")
-SOURCES = ["gemm", "gemm_pp", "gemm_256", "gemm_stream", "gemv", "attention", "norm", "elementwise", "conv", "loss", "lowrank", "lora", "expert", "image", "optim", "version"]
+SOURCES = ["gemm", "gemm_pp", "gemm_256", "gemm_stream", "gemv", "attention", "attn_seq", "norm", "elementwise", "conv", "loss", "lowrank", "lora", "expert", "image", "optim", "version"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
 
 
@@ -24,12 +24,12 @@ def _stale(out, deps):
 def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
-    hdr = os.path.join(CSRC, "common.h")
+    hdrs = [os.path.join(CSRC, "common.h")]
 
     def one(name):
         src = os.path.join(CSRC, name + ".hip")
         obj = os.path.join(OBJ, name + ".o")
-        if force or _stale(obj, [src, hdr]):
+        if force or _stale(obj, [src, *hdrs]):
             cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
             if verbose:
                 print(" ".join(cmd), flush=True)

@@ -715,6 +715,45 @@ extern "C" int mh_gemm_rmsnorm_bwd(const void* A, int lda, const void* B, int ld
   return mh_launch_rmsnorm_bwd(dy_buf, 1, 0, N, x, w, dres, dx, dx_bf16, M, N, eps, stream);
 }
 
+int mh_launch_attn_rope_bwd(const void* qkv, int ld, const void* o, int ldo, const void* dout, int dout_is_bf16, int nslab,
+                            long slab, int ldd, const float* lse, void* dqkv, const int* pos, const float* cos_tab,
+                            const float* sin_tab, const int* kv_len, int B, int H, int S, int D, float scale,
+                            hipStream_t stream);
+
+// dO[M = B*S, N = H*D] = A.Bw^T (the o_proj dgrad, modeling_llama.py:222-224 under autograd), then the fused rotary
+// attention backward that consumes it (attn_seq.hip).  When the policy splits K the attention kernel sums the partial
+// slabs itself while it loads its dO rows (the same fixed order and single rounding as splitk_reduce_kernel, so the same
+// bits as mh_gemm_bf16_nt + mh_attn_rope_bwd); otherwise dO goes through do_buf [M, N] bf16.
+extern "C" int mh_gemm_attn_rope_bwd(const void* A, int lda, const void* Bw, int ldb, void* do_buf, int K, const void* qkv,
+                                     int ld, const void* o, int ldo, const float* lse, void* dqkv, const int* pos,
+                                     const float* cos_tab, const float* sin_tab, const int* kv_len, int B, int H, int S,
+                                     int D, float scale, hipStream_t stream) {
+  const int M = B * S, N = H * D;
+  if (M <= 0 || N <= 0) return MH_OK;
+  if (!do_buf) return MH_ERR_ARG;
+  int kernel = 1, splits = 1;
+  if (K > 0) gemm_plan(M, N, K, MH_GEMM_OUT_F32, &kernel, &splits);
+  if (splits > 1 && kernel != 0 && (K % 64) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && (N % 8) == 0 &&
+      !(((uintptr_t)A | (uintptr_t)Bw) & 15)) {
+    GemmArgs g = {A, lda, Bw, ldb, do_buf, N, M, N, K, nullptr, nullptr, 0, MH_GEMM_OUT_F32, 1.0f, 1, K / 64, 0L};
+    if (kernel == 2) g.flags |= 12 << MH_GEMM_VARIANT_SHIFT;
+    if (kernel == 3) g.flags |= 13 << MH_GEMM_VARIANT_SHIFT;
+    const int nt = K / 64;                          // the split count run_splitk will settle on
+    int sp = splits > nt ? nt : splits;
+    const int tps = (nt + sp - 1) / sp;
+    sp = (nt + tps - 1) / tps;
+    float* wsp = ws_for(stream);
+    const int rc = run_splitk(g, splits, wsp, stream, /*reduce=*/false);
+    if (rc) return rc;
+    return mh_launch_attn_rope_bwd(qkv, ld, o, ldo, wsp, 0, sp, (long)M * N, N, lse, dqkv, pos, cos_tab, sin_tab, kv_len, B, H, S,
+                                   D, scale, stream);
+  }
+  const int rc = mh_gemm_bf16_nt(A, lda, Bw, ldb, do_buf, N, M, N, K, nullptr, nullptr, 0, 0, 1.0f, stream);
+  if (rc) return rc;
+  return mh_launch_attn_rope_bwd(qkv, ld, o, ldo, do_buf, 1, 1, 0, N, lse, dqkv, pos, cos_tab, sin_tab, kv_len, B, H, S, D, scale,
+                                 stream);
+}
+
 // ---- explicit split-K entry (wgrad of the conv stem: M,N small, K huge); caller passes the scratch ----
 extern "C" long mh_gemm_splitk_ws_floats(int M, int N, int splits) { return (long)M * N * splits; }
 

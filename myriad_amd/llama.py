@@ -135,6 +135,9 @@ class LlamaHIP:
                 return None
             return lora.x_ext(li, M)[:, :D]
 
+        # whole-sequence attention with the rotary embedding fused (csrc/attn_seq.hip) when the sequence fits a CU's LDS:
+        # qkv is then saved PRE-rotary and the backward kernel rotates again / un-rotates dq, dk itself
+        fused_attn = ops.attn_rope_supported(S, hd) and os.environ.get("MYRIAD_ATTN_SEQ", "1") != "0"
         xn = ops.rmsnorm_fwd(h, self.layers[0]["ln1"], self.eps, out=norm_target(0)) if self.layers else None
         for li, L in enumerate(self.layers):
             lsave = None
@@ -145,10 +148,13 @@ class LlamaHIP:
                 p_eff, seed = lora.forward_border(li, x_ext)
                 qkv = ops.gemm(x_ext, L["wqkv_ext"])
                 lsave = (x_ext, p_eff, seed)
-            ops.rope_(qkv, 0, 2 * H, hd, pos, self.cos, self.sin, 1.0)      # q and k heads
             q3 = qkv.view(B, S, 3 * W)
-            o, lse = ops.attn_fwd(q3[:, :, :W], q3[:, :, W:2 * W], q3[:, :, 2 * W:], H, hd, scale, causal=True,
-                                  kv_len=kv_len)
+            if fused_attn:
+                o, lse = ops.attn_rope_fwd(q3, H, hd, scale, pos, self.cos, self.sin, kv_len=kv_len)
+            else:
+                ops.rope_(qkv, 0, 2 * H, hd, pos, self.cos, self.sin, 1.0)  # q and k heads
+                o, lse = ops.attn_fwd(q3[:, :, :W], q3[:, :, W:2 * W], q3[:, :, 2 * W:], H, hd, scale, causal=True,
+                                      kv_len=kv_len)
             h2, xn2 = ops.gemm_residual_rmsnorm(o.view(M, W), L["wo"], h, L["ln2"], self.eps)
             gu = ops.gemm(xn2, L["wgu"])                                    # [M, 2I]
             act = ops.silu_mul_fwd(gu)
@@ -176,7 +182,7 @@ class LlamaHIP:
         loss = ops.sum_f32(row_loss, 1.0 / n_valid)
         if save_for_backward:
             self._saved = dict(layers=saved, rows=rows, hr=hr, dlogits=dlogits, B=B, S=S, kv_len=kv_len, pos=pos,
-                               scale=scale)
+                               scale=scale, fused_attn=fused_attn)
         return loss.view(())
 
     # ------------------------------------------------------------------ dgrad-only backward
@@ -204,14 +210,19 @@ class LlamaHIP:
             dgu = ops.silu_mul_bwd(dact, gu)
             # gate|up dgrad [M, D] and the post-attention norm's backward in one call (split-K slabs summed in the norm kernel)
             dh2, dh2_b = ops.gemm_rmsnorm_bwd(dgu, L["wguT"], h2, L["ln2"], self.eps, dres=dh)
-            do = ops.gemm(dh2_b, L["woT"])                                  # [M, W] bf16
             q3 = qkv.view(B, S, 3 * W)
             dqkv = torch.empty_like(qkv)
             d3 = dqkv.view(B, S, 3 * W)
-            ops.attn_bwd(q3[:, :, :W], q3[:, :, W:2 * W], q3[:, :, 2 * W:], o, do.view(B, S, W), lse, H, hd,
-                         sv["scale"], causal=True, kv_len=sv["kv_len"], dq=d3[:, :, :W], dk=d3[:, :, W:2 * W],
-                         dv=d3[:, :, 2 * W:])
-            ops.rope_(dqkv, 0, 2 * H, hd, sv["pos"], self.cos, self.sin, -1.0)
+            if sv["fused_attn"]:
+                # o_proj dgrad + attention backward: the split-K slabs of dO are summed inside the attention kernel
+                ops.gemm_attn_rope_bwd(dh2_b, L["woT"], q3, o, lse, H, hd, sv["scale"], sv["pos"], self.cos, self.sin,
+                                       kv_len=sv["kv_len"], dqkv=d3)
+            else:
+                do = ops.gemm(dh2_b, L["woT"])                              # [M, W] bf16
+                ops.attn_bwd(q3[:, :, :W], q3[:, :, W:2 * W], q3[:, :, 2 * W:], o, do.view(B, S, W), lse, H, hd,
+                             sv["scale"], causal=True, kv_len=sv["kv_len"], dq=d3[:, :, :W], dk=d3[:, :, W:2 * W],
+                             dv=d3[:, :, 2 * W:])
+                ops.rope_(dqkv, 0, 2 * H, hd, sv["pos"], self.cos, self.sin, -1.0)
             if self.lora is None:
                 dxn = ops.gemm(dqkv, L["wqkvT"], out_dtype=F32)
             else:

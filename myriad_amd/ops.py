@@ -266,6 +266,65 @@ def attn_bwd(q, k, v, o, dout, lse, H: int, D: int, scale: float, causal: bool =
     return dq, dk, dv
 
 
+def attn_rope_supported(S: int, D: int) -> bool:
+    """Whether the whole-sequence fused rotary attention (mh_attn_rope_*) covers this shape."""
+    return bool(_L().mh_attn_rope_supported(int(S), int(D)))
+
+
+def _chk_qkv3(qkv3, H, D, name):
+    if qkv3.dtype != BF16 or qkv3.dim() != 3 or qkv3.stride(2) != 1 or qkv3.stride(0) != qkv3.shape[1] * qkv3.stride(1):
+        raise _lib.MyriadHipError(f"{name}: need bf16 [B, S, >=3*H*D] with unit inner stride and dense batches")
+    if qkv3.shape[2] < 3 * H * D:
+        raise _lib.MyriadHipError(f"{name}: last dim {qkv3.shape[2]} < 3*H*D")
+
+
+def attn_rope_fwd(qkv3: torch.Tensor, H: int, D: int, scale: float, pos, cos, sin, kv_len=None, need_lse: bool = True):
+    """LLaMA causal self-attention with rotary applied on load.  qkv3 [B, S, >=3W] bf16 = [q | k | v], PRE-rotary.
+    Returns (o [B, S, W] bf16, lse [B, H, S] f32)."""
+    _chk_qkv3(qkv3, H, D, "attn_rope_fwd")
+    B, S = qkv3.shape[0], qkv3.shape[1]
+    o = torch.empty((B, S, H * D), dtype=BF16, device=qkv3.device)
+    lse = torch.empty((B, H, S), dtype=F32, device=qkv3.device) if need_lse else None
+    rc = _L().mh_attn_rope_fwd(_p(qkv3), qkv3.stride(1), _p(o), o.stride(1), _p(lse), _p(pos), _p(cos), _p(sin), _p(kv_len),
+                               B, H, S, D, float(scale), _s())
+    _lib.check(rc, f"mh_attn_rope_fwd B={B} H={H} S={S} D={D}")
+    return o, lse
+
+
+def attn_rope_bwd(qkv3, o, dout, lse, H: int, D: int, scale: float, pos, cos, sin, kv_len=None, dqkv=None):
+    """Backward of attn_rope_fwd: dqkv [B, S, ld] = [dq | dk | dv] (dq, dk un-rotated).  dout [B*S or B,S, W] bf16."""
+    _chk_qkv3(qkv3, H, D, "attn_rope_bwd")
+    B, S = qkv3.shape[0], qkv3.shape[1]
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv3)
+    d2 = dout.reshape(B * S, -1)
+    _chk2d(d2, BF16, "attn_rope_bwd.dout")
+    rc = _L().mh_attn_rope_bwd(_p(qkv3), qkv3.stride(1), _p(o), o.stride(1), _p(d2), d2.stride(0), _p(lse), _p(dqkv),
+                               _p(pos), _p(cos), _p(sin), _p(kv_len), B, H, S, D, float(scale), _s())
+    _lib.check(rc, f"mh_attn_rope_bwd B={B} H={H} S={S} D={D}")
+    return dqkv
+
+
+def gemm_attn_rope_bwd(a, bw, qkv3, o, lse, H: int, D: int, scale: float, pos, cos, sin, kv_len=None, dqkv=None):
+    """dO = a @ bw^T (the o_proj dgrad) and the fused rotary attention backward that consumes it; when the GEMM policy
+    splits K the attention kernel sums the partial slabs itself.  Same bits as gemm() + attn_rope_bwd()."""
+    _chk_qkv3(qkv3, H, D, "gemm_attn_rope_bwd")
+    _chk2d(a, BF16, "gemm_attn_rope_bwd.a")
+    _chk2d(bw, BF16, "gemm_attn_rope_bwd.bw")
+    B, S = qkv3.shape[0], qkv3.shape[1]
+    M, K = a.shape
+    if M != B * S or bw.shape != (H * D, K):
+        raise _lib.MyriadHipError(f"gemm_attn_rope_bwd: a {tuple(a.shape)} bw {tuple(bw.shape)} vs B*S={B * S} W={H * D}")
+    if dqkv is None:
+        dqkv = torch.empty_like(qkv3)
+    do_buf = torch.empty((M, H * D), dtype=BF16, device=a.device)
+    rc = _L().mh_gemm_attn_rope_bwd(_p(a), a.stride(0), _p(bw), bw.stride(0), _p(do_buf), K, _p(qkv3), qkv3.stride(1), _p(o),
+                                    o.stride(1), _p(lse), _p(dqkv), _p(pos), _p(cos), _p(sin), _p(kv_len), B, H, S, D,
+                                    float(scale), _s())
+    _lib.check(rc, f"mh_gemm_attn_rope_bwd M={M} K={K} H={H} S={S}")
+    return dqkv
+
+
 # --------------------------------------------------------------------------- norms
 def rmsnorm_fwd(x: torch.Tensor, w: torch.Tensor, eps: float, out=None):
     """out may be a [M, D] view of a wider bf16 buffer (row stride >= D)."""

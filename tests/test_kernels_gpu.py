@@ -334,6 +334,88 @@ def test_attention_online_softmax_spike():
     assert relerr(o.float(), ref) < 1.5e-2
 
 
+def _rope_tables(D, max_pos=256):
+    inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
+    fr = torch.einsum("i,j->ij", torch.arange(max_pos).float(), inv)
+    return fr.cos().contiguous().to(DEV), fr.sin().contiguous().to(DEV)
+
+
+def _rope_ref(x, pos, cos, sin):
+    """reference modeling_llama.py:109-123: x [B,H,S,D] fp32, rotate-half form."""
+    D = x.shape[-1]
+    c = torch.cat([cos[pos], cos[pos]], -1)[:, None]      # [B,1,S,D]
+    s_ = torch.cat([sin[pos], sin[pos]], -1)[:, None]
+    rot = torch.cat([-x[..., D // 2:], x[..., :D // 2]], -1)
+    return x * c + rot * s_
+
+
+@pytest.mark.parametrize("B,H,S,ragged,border", [(2, 3, 148, False, 64), (2, 2, 160, True, 0), (1, 4, 81, False, 0),
+                                                 (3, 2, 17, True, 64), (1, 1, 1, False, 0), (2, 2, 99, True, 0)])
+def test_attention_rope_whole_sequence(B, H, S, ragged, border):
+    """mh_attn_rope_fwd/bwd (rotary fused, one workgroup per (b, h)) vs an fp32 torch model of
+    apply_rotary_pos_emb + LlamaAttention (modeling_llama.py:109-123, 168-231), and vs the tile kernels + mh_rope_inplace."""
+    D = 128
+    W = H * D
+    assert ops.attn_rope_supported(S, D)
+    ld = 3 * W + border                                  # the LoRA-bordered qkv GEMM output has a wider row
+    qkv_full = bf(rnd(B, S, ld, seed=51)).to(DEV)
+    qkv = qkv_full[:, :, :ld]
+    cos, sin = _rope_tables(D)
+    pos = (torch.arange(S, dtype=torch.int32)[None] + torch.arange(B, dtype=torch.int32)[:, None] * 3).contiguous().to(DEV)
+    kv_len = None
+    if ragged:
+        kv_len = torch.tensor([max(1, S - (5 * i + 2) % max(1, S // 2)) for i in range(B)], dtype=torch.int32, device=DEV)
+    scale = D ** -0.5
+    o, lse = ops.attn_rope_fwd(qkv, H, D, scale, pos.view(-1), cos, sin, kv_len=kv_len)
+
+    def heads(t):
+        return t.float().reshape(B, S, H, D).transpose(1, 2).detach().requires_grad_(True)
+
+    qf, kf, vf = heads(qkv[:, :, :W]), heads(qkv[:, :, W:2 * W]), heads(qkv[:, :, 2 * W:3 * W])
+    pl = pos.long()
+    ref = attn_ref(_rope_ref(qf, pl, cos, sin), _rope_ref(kf, pl, cos, sin), vf, scale, True, None,
+                   None if kv_len is None else kv_len.long())
+    ref_tok = ref.transpose(1, 2).reshape(B, S, W)
+    valid = torch.ones(B, S, dtype=torch.bool, device=DEV)
+    if kv_len is not None:
+        valid = torch.arange(S, device=DEV)[None] < kv_len[:, None]
+    assert relerr(o.float()[valid], ref_tok[valid]) < 1.5e-2
+    # the tile kernels on the rotated copy give the same attention (both round q, k to bf16 after the rotation)
+    rot = qkv.contiguous().clone()
+    ops.rope_(rot.view(B * S, ld), 0, 2 * H, D, pos.view(-1), cos, sin, 1.0)
+    o2, lse2 = ops.attn_fwd(rot[:, :, :W], rot[:, :, W:2 * W], rot[:, :, 2 * W:3 * W], H, D, scale, causal=True, kv_len=kv_len)
+    assert relerr(o.float()[valid], o2.float()[valid]) < 8e-3
+    assert relerr(lse.transpose(1, 2)[valid], lse2.transpose(1, 2)[valid]) < 2e-3
+    if S == 1:
+        return
+    dout = bf(rnd(B, S, W, seed=52)).to(DEV) * valid[..., None]
+    dqkv = ops.attn_rope_bwd(qkv, o, dout, lse, H, D, scale, pos.view(-1), cos, sin, kv_len=kv_len)
+    (ref_tok * dout.float()).sum().backward()
+    for i, (want, nm) in enumerate(((qf.grad, "dq"), (kf.grad, "dk"), (vf.grad, "dv"))):
+        want_tok = want.transpose(1, 2).reshape(B, S, W)
+        got = dqkv[:, :, i * W:(i + 1) * W].float()
+        assert relerr(got[valid], want_tok[valid]) < 2.5e-2, nm
+
+
+def test_gemm_attention_rope_bwd_reads_split_k_slabs():
+    """mh_gemm_attn_rope_bwd: the o_proj dgrad's split-K slabs summed inside the attention backward == gemm + attn_rope_bwd."""
+    ops.ensure_workspace(torch.device(DEV))
+    B, H, S, D = 8, 32, 148, 128
+    W = H * D
+    qkv = bf(rnd(B, S, 3 * W + 64, seed=61, scale=0.5)).to(DEV)
+    cos, sin = _rope_tables(D)
+    pos = torch.arange(S, dtype=torch.int32).repeat(B).to(DEV)
+    scale = D ** -0.5
+    o, lse = ops.attn_rope_fwd(qkv, H, D, scale, pos, cos, sin)
+    a = bf(rnd(B * S, W, seed=62, scale=0.1)).to(DEV)
+    bw = bf(rnd(W, W, seed=63, scale=0.05)).to(DEV)
+    assert ops.gemm_plan(B * S, W, W, out_f32=True)[1] > 1       # the policy splits K for this shape
+    do = ops.gemm(a, bw)
+    want = ops.attn_rope_bwd(qkv, o, do, lse, H, D, scale, pos, cos, sin)
+    got = ops.gemm_attn_rope_bwd(a, bw, qkv, o, lse, H, D, scale, pos, cos, sin)
+    assert torch.equal(got[:, :, :3 * W], want[:, :, :3 * W])
+
+
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("M,D", [(37, 4096), (5, 64), (300, 1408)])
 def test_rmsnorm(M, D):

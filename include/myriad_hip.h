@@ -159,6 +159,10 @@ int mh_clamp_ce(const float* logits, long ldl, const long* labels, float* row_lo
 int mh_sum_f32(const float* x, float* out, long n, float scale, mh_stream_t s);
 /* greedy step (evaluation_aqa_dataset.py:289-301 top_p=0.01 == arg-max; min_length ban of EOS) */
 int mh_argmax_rows(const float* logits, long ldl, long* out, float* margin, int R, int V, int ban_id, mh_stream_t s);
+/* the same plus p_max[row] = softmax(logits * inv_temp)[argmax] (banned id excluded): tells whether HF's
+   `do_sample=True, top_p=p` is the arg-max (p_max >= p keeps exactly one token) -- generation_kwargs of the eval script */
+int mh_argmax_pmax_rows(const float* logits, long ldl, long* out, float* margin, float* pmax, int R, int V, int ban_id,
+                        float inv_temp, mh_stream_t s);
 
 /* K12 conv stacks of VEInstructorV2 / VETokenizer (networks.py:98-127,159-189) as im2col + mh_gemm_bf16_nt. */
 int mh_im2col_nhwc(const void* x, void* col, int B, int H, int W, int C, int kh, int kw, int pad, int Kpad,
@@ -214,6 +218,15 @@ int mh_scale_f32(float* x, float a, long n, mh_stream_t s);
 /* K15 AdamW (runner_base.py:104-139) on a flat f32 buffer with optional bf16 shadow; step is 1-based. */
 int mh_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, double lr, double beta1,
                   double beta2, double eps, double weight_decay, int step, double grad_scale, mh_stream_t s);
+
+/* Gated AdamW: torch.optim.AdamW skips parameters whose .grad is None -- a module no rank used this step (random prompt
+   stage, myriad.py:378; DDP find_unused_parameters, runner_base.py:96-98) keeps its parameters, moments and step count.
+   used/steps are DEVICE scalars (use count summed over ranks by the gradient all-reduce; updates applied so far):
+   mh_adamw_gated updates one contiguous range iff *used > 0 with step = *steps + 1 (bias corrections in double);
+   mh_adamw_bump(used[n], steps[n]) then advances the counters of the used modules. */
+int mh_adamw_gated(float* p, const float* g, float* m, float* v, long n, double lr, double beta1, double beta2, double eps,
+                   double weight_decay, double grad_scale, const float* used, const int* steps, mh_stream_t s);
+int mh_adamw_bump(const float* used, int* steps, int n, mh_stream_t s);
 
 /* K16 anomaly-map heads of the vision expert (adrefexpert_v2.py:243-301).  All f32.
  * l2norm_rows: y = x / max(||x||, eps) (bf16 and/or f32 out) -- operands of the cosine similarities (:259, :283);

@@ -115,41 +115,176 @@ def assemble_reference_weights(eva_vit: Optional[Mapping] = None, qformer: Optio
     return out
 
 
+# ------------------------------------------------------------------------------------------------ the reference's weight sources
+EVA_VIT_URL_BASENAME = "eva_vit_g.pth"          # eva_vit.py:430 downloads .../BLIP2/eva_vit_g.pth into the hub cache
+MINIGPT4_PROJ_PATH = "./pretrained_models/pretrained_minigpt4_7b.pth"      # hard-coded at myriad.py:210
+
+
+def _hub_dirs() -> List[str]:
+    dirs = []
+    if os.environ.get("TORCH_HOME"):
+        dirs.append(os.path.join(os.environ["TORCH_HOME"], "hub", "checkpoints"))
+    dirs.append(os.path.join(os.path.expanduser("~"), ".cache", "torch", "hub", "checkpoints"))
+    dirs.append("./pretrained_models")
+    return dirs
+
+
+def resolve_checkpoint_file(url_or_filename: str) -> str:
+    """`load_from_pretrained` (blip2.py:91-110) / `download_cached_file` (dist_utils.py:93-137) without the network:
+    a file path is used as is; a URL maps to its basename in the torch hub cache (where the reference's download
+    would have put it) or ./pretrained_models."""
+    if os.path.isfile(url_or_filename):
+        return url_or_filename
+    if "://" in url_or_filename:
+        base = os.path.basename(url_or_filename.split("?")[0])
+        for d in _hub_dirs():
+            cand = os.path.join(d, base)
+            if os.path.isfile(cand):
+                return cand
+        raise RuntimeError(f"checkpoint url or path is invalid: {url_or_filename} is a URL, this build does not download; "
+                           f"put {base} into one of {_hub_dirs()}")
+    raise RuntimeError(f"checkpoint url or path is invalid: {url_or_filename}")
+
+
+def load_llama_tokenizer(llama_model: str):
+    """myriad.py:182-183: `LlamaTokenizer.from_pretrained(llama_model, use_fast=False)`, pad_token = eos_token."""
+    from transformers import LlamaTokenizer
+    tok = LlamaTokenizer.from_pretrained(llama_model, use_fast=False)
+    tok.pad_token = tok.eos_token
+    return tok
+
+
+def load_reference_weights(cfg, arch: str = "myriad"):
+    """Everything `Myriad.__init__` / `MiniGPT4.__init__` load from disk (myriad.py:104-217, mini_gpt4.py:43-121), from the
+    reference's own config keys: `vit_model` ("eva_clip_g" or a file), `q_former_model` (URL or file), `llama_model` (HF
+    directory), the MiniGPT-4 projection file.  Returns (weights keyed by the reference's state_dict names, meta)."""
+    get = cfg.get if hasattr(cfg, "get") else (lambda k, d=None: getattr(cfg, k, d))
+    llama_dir = get("llama_model")
+    if not llama_dir or not os.path.isdir(llama_dir):
+        raise FileNotFoundError(f"model.llama_model must be a HuggingFace checkpoint directory, got {llama_dir!r}")
+    hf_cfg = json.load(open(os.path.join(llama_dir, "config.json")))
+    vit_model = get("vit_model", "eva_clip_g")
+    if vit_model == "eva_clip_g":
+        vit_path = get("vit_ckpt") or resolve_checkpoint_file("https://hub/" + EVA_VIT_URL_BASENAME)
+    elif os.path.isfile(str(vit_model)):
+        vit_path = vit_model
+    else:
+        raise AssertionError("vit model must be eva_clip_g (or a path to its state dict)")      # blip2.py:68-70
+    qf_path = resolve_checkpoint_file(get("q_former_model", "https://storage.googleapis.com/sfr-vision-language-research/"
+                                                            "LAVIS/models/BLIP2/blip2_pretrained_flant5xxl.pth"))
+    image_size = int(get("image_size", 224))
+    vit_sd = torch.load(vit_path, map_location="cpu")
+    depth = int(get("vit_depth", 39))             # create_eva_vit_g builds depth=39 and loads strict=False (eva_vit.py:421,436)
+    vit_sd = {k: v for k, v in (vit_sd["model"] if "model" in vit_sd and isinstance(vit_sd["model"], Mapping) else vit_sd).items()
+              if not (k.startswith("blocks.") and int(k.split(".")[1]) >= depth)}
+    n_blocks = len({k.split(".")[1] for k in vit_sd if k.startswith("blocks.")})
+    if n_blocks != depth:
+        raise ValueError(f"EVA ViT checkpoint has {n_blocks} of the {depth} blocks the reference builds")
+    proj = None
+    proj_path = get("minigpt4_ckpt", MINIGPT4_PROJ_PATH)
+    if arch == "myriad" or os.path.isfile(proj_path):
+        if not os.path.isfile(proj_path):
+            raise FileNotFoundError(f"{proj_path}: Myriad loads llama_proj from it (myriad.py:210-217)")
+        proj = torch.load(proj_path, map_location="cpu")
+    weights = assemble_reference_weights(eva_vit=vit_sd, qformer=torch.load(qf_path, map_location="cpu"), minigpt4=proj,
+                                         llama=load_hf_shards(llama_dir), num_patches=(image_size // 14) ** 2)
+    meta = dict(llm_heads=int(hf_cfg.get("num_attention_heads", 32)), llm_eps=float(hf_cfg.get("rms_norm_eps", 1e-6)),
+                bos_token_id=int(hf_cfg.get("bos_token_id", 1)), pad_token_id=int(hf_cfg.get("eos_token_id", 2)),
+                vit_heads=16, qf_heads=12)
+    return weights, meta
+
+
 # ------------------------------------------------------------------------------------------------ fine-tune checkpoints
+def reference_param_order(names) -> List[str]:
+    """The trainable parameters in the order `model.named_parameters()` yields them in the REFERENCE -- the order
+    `RunnerBase.optimizer` builds its two param groups in (runner_base.py:110-119) and therefore the indices of
+    torch.optim.AdamW's state_dict.  nn.Module yields a module's own parameters before its children's, children in
+    registration order: Myriad.__init__ registers expert_adaptor, VETokenizer (direct parameter `base_prompts` before
+    `meta_net.*`), VEInstructor, Qformer, llama_model (peft: per layer q_proj.lora_A, q_proj.lora_B, v_proj.lora_A,
+    v_proj.lora_B), llama_proj (myriad.py:117-125, 148, 186-207)."""
+    import re
+
+    def key(n: str):
+        if n.startswith("expert_adaptor."):
+            return (0, 0 if ".conv1." in n else 1, 0, 0)
+        for rank, pre in ((1, "VETokenizer."), (2, "VEInstructor.")):
+            if n.startswith(pre):
+                if n.endswith("base_prompts"):
+                    return (rank, -1, 0, 0)
+                m = re.search(r"meta_net\.(\d+)\.(weight|bias)$", n)
+                return (rank, int(m.group(1)), 0 if m.group(2) == "weight" else 1, 0)
+        if "lora_" in n:
+            m = re.search(r"layers\.(\d+)\.self_attn\.([qv])_proj\.lora_([AB])\.", n)
+            return (3, int(m.group(1)), 0 if m.group(2) == "q" else 1, 0 if m.group(3) == "A" else 1)
+        if n.startswith("llama_proj."):
+            return (4, 0 if n.endswith("weight") else 1, 0, 0)
+        raise KeyError(n)
+
+    return sorted(names, key=key)
+
+
+def _optimizer_index(store) -> List[str]:
+    """Parameter name of each torch optimizer index: weight-decay group first, then the rest, each in reference order."""
+    from .myriad import uses_weight_decay
+    names = reference_param_order([n for n, _, _ in store.specs])
+    shapes = {n: r for n, _, r in store.specs}
+    wd = [n for n in names if uses_weight_decay(n, len(shapes[n]))]
+    return wd + [n for n in names if n not in set(wd)], len(wd)
+
+
 def optimizer_state_dict(store, lr: float, weight_decay: float = 0.05, betas=(0.9, 0.999), eps: float = 1e-8) -> dict:
-    """The flat AdamW state as torch.optim.AdamW.state_dict() would hold it for `RunnerBase.optimizer`'s two groups."""
-    state, idx, groups = {}, 0, [[], []]
-    n_wd_params = sum(1 for name, _, rshape in store.specs if store.offsets[name][0] < store.n_wd)
-    for name, ishape, rshape in store.specs:
+    """The flat AdamW state as torch.optim.AdamW.state_dict() holds it for `RunnerBase.optimizer`'s two groups
+    (runner_base.py:104-139): indices follow the reference's named_parameters() order, NOT the flat buffer's; a module
+    that was never stepped has no state entry (torch creates state lazily), each entry carries its module's own step."""
+    from .myriad import module_of
+    order, n_wd = _optimizer_index(store)
+    ishape = {n: i for n, i, _ in store.specs}
+    rshape = {n: r for n, _, r in store.specs}
+    steps = store.module_steps()
+    state, groups = {}, [[], []]
+    for idx, name in enumerate(order):
         o, n = store.offsets[name]
-        state[idx] = {"step": torch.tensor(float(store.step)),
-                      "exp_avg": to_reference_layout(store.flat_m[o:o + n].view(ishape), rshape).cpu().clone(),
-                      "exp_avg_sq": to_reference_layout(store.flat_v[o:o + n].view(ishape), rshape).cpu().clone()}
-        groups[0 if idx < n_wd_params else 1].append(idx)
-        idx += 1
+        st = steps.get(module_of(name), 0)
+        if st > 0:
+            state[idx] = {"step": torch.tensor(float(st)),
+                          "exp_avg": to_reference_layout(store.flat_m[o:o + n].view(ishape[name]), rshape[name]).cpu().clone(),
+                          "exp_avg_sq": to_reference_layout(store.flat_v[o:o + n].view(ishape[name]), rshape[name]).cpu().clone()}
+        groups[0 if idx < n_wd else 1].append(idx)
     common = dict(lr=lr, betas=tuple(betas), eps=eps, amsgrad=False, maximize=False, foreach=None, capturable=False,
                   differentiable=False, fused=None)
-    return {"state": state,
-            "param_groups": [dict(common, weight_decay=weight_decay, params=groups[0]),
-                             dict(common, weight_decay=0.0, params=groups[1])]}
+    pg = []
+    if groups[0]:
+        pg.append(dict(common, weight_decay=weight_decay, params=groups[0]))
+    if groups[1]:
+        pg.append(dict(common, weight_decay=0.0, params=groups[1]))
+    return {"state": state, "param_groups": pg}
 
 
 def load_optimizer_state_dict(store, sd: dict) -> None:
-    names = [name for name, _, _ in store.specs]
-    order: List[int] = [i for g in sd["param_groups"] for i in g["params"]]
-    if len(order) != len(names):
-        raise ValueError(f"optimizer state has {len(order)} parameters, the model {len(names)}")
-    step = 0
-    for pos, idx in enumerate(order):
-        name, ishape, _ = store.specs[pos]
+    """Inverse of optimizer_state_dict: accepts what the reference's runner saved (`self.optimizer.state_dict()`,
+    runner_base.py:606-612)."""
+    from .myriad import module_of
+    order, _ = _optimizer_index(store)
+    flat: List[int] = [i for g in sd["param_groups"] for i in g["params"]]
+    if len(flat) != len(order):
+        raise ValueError(f"optimizer state has {len(flat)} parameters, the model {len(order)}")
+    ishape = {n: i for n, i, _ in store.specs}
+    steps: Dict[str, int] = {}
+    for pos, idx in enumerate(flat):
+        name = order[pos]
         st = sd["state"].get(idx, sd["state"].get(str(idx)))
         if st is None:
             continue                                   # parameter never stepped (torch creates state lazily)
         o, n = store.offsets[name]
-        store.flat_m[o:o + n].view(ishape).copy_(from_reference_layout(st["exp_avg"].to(store.flat_m.device, torch.float32), ishape))
-        store.flat_v[o:o + n].view(ishape).copy_(from_reference_layout(st["exp_avg_sq"].to(store.flat_v.device, torch.float32), ishape))
-        step = max(step, int(float(st["step"])))
-    store.step = step
+        if tuple(st["exp_avg"].shape) != tuple({n_: r for n_, _, r in store.specs}[name]):
+            raise ValueError(f"optimizer state {idx} has shape {tuple(st['exp_avg'].shape)}, parameter {name} "
+                             f"{tuple({n_: r for n_, _, r in store.specs}[name])}: parameter order mismatch")
+        store.flat_m[o:o + n].view(ishape[name]).copy_(from_reference_layout(st["exp_avg"].to(store.flat_m.device, torch.float32), ishape[name]))
+        store.flat_v[o:o + n].view(ishape[name]).copy_(from_reference_layout(st["exp_avg_sq"].to(store.flat_v.device, torch.float32), ishape[name]))
+        m = module_of(name)
+        steps[m] = max(steps.get(m, 0), int(float(st["step"])))
+    store.set_module_steps(steps)
+    store.step = max(steps.values()) if steps else 0
 
 
 class CheckpointManager:

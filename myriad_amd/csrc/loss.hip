@@ -108,3 +108,27 @@ extern "C" int mh_argmax_rows(const float* logits, long ldl, long* out, float* m
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
+// p_max of each row after the arg-max is known: 1 / sum_j exp((x_j - best) * inv_temp), banned id excluded.  The decode loop
+// uses it to decide whether the reference's `do_sample=True, top_p=p` call (evaluation_aqa_dataset.py:289-301) is the
+// arg-max (HF's top-p warper keeps only the first token whenever p_max >= top_p) or a real draw.
+__global__ __launch_bounds__(LNT) void pmax_kernel(const float* __restrict__ logits, long ldl, const long* __restrict__ best_id,
+                                                   float* __restrict__ pmax, int V, int ban_id, float inv_temp) {
+  __shared__ float red[LNW];
+  const long row = blockIdx.x;
+  const float* x = logits + row * ldl;
+  const float best = x[best_id[row]];
+  float s = 0.f;
+  for (int j = threadIdx.x; j < V; j += LNT)
+    if (j != ban_id) s += __expf((x[j] - best) * inv_temp);
+  s = block_sum<LNW>(s, red);
+  if (threadIdx.x == 0) pmax[row] = 1.f / s;
+}
+extern "C" int mh_argmax_pmax_rows(const float* logits, long ldl, long* out, float* margin, float* pmax, int R, int V,
+                                   int ban_id, float inv_temp, hipStream_t stream) {
+  if (R <= 0) return MH_OK;
+  if (!out || !pmax) return MH_ERR_ARG;
+  hipLaunchKernelGGL(argmax_kernel, dim3(R), dim3(LNT), 0, stream, logits, ldl, out, margin, V, ban_id);
+  hipLaunchKernelGGL(pmax_kernel, dim3(R), dim3(LNT), 0, stream, logits, ldl, out, pmax, V, ban_id, inv_temp);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}

@@ -109,7 +109,7 @@ class LlamaHIP:
 
     # ------------------------------------------------------------------ training forward
     def forward_loss(self, x: torch.Tensor, attention_mask: torch.Tensor, labels: torch.Tensor,
-                     save_for_backward: bool = True) -> torch.Tensor:
+                     save_for_backward: bool = True, lora_training: Optional[bool] = None) -> torch.Tensor:
         """x: [B,S,D] f32 inputs_embeds (device); attention_mask/labels: [B,S] CPU or device int64.
         Returns the 0-d f32 loss tensor (device).  Stores what `backward()` needs."""
         B, S, D = x.shape
@@ -145,7 +145,8 @@ class LlamaHIP:
                 qkv = ops.gemm(xn, L["wqkv"])                               # [M, 3W] bf16
             else:   # q/v LoRA rides the qkv GEMM as a 64-column K border (myriad_amd/lora.py)
                 x_ext = lora.x_ext(li, M)                                   # [:, :D] already holds rmsnorm(h)
-                p_eff, seed = lora.forward_border(li, x_ext)
+                p_eff, seed = lora.forward_border(li, x_ext, training=save_for_backward if lora_training is None
+                                                  else lora_training)
                 qkv = ops.gemm(x_ext, L["wqkv_ext"])
                 lsave = (x_ext, p_eff, seed)
             q3 = qkv.view(B, S, 3 * W)
@@ -284,18 +285,28 @@ class LlamaHIP:
     @torch.no_grad()
     def greedy_generate(self, inputs_embeds: torch.Tensor, max_new_tokens: int = 90,
                         stop_ids=((835,), (2277, 29937)), eos_id: int = 2, min_length: int = 1,
-                        return_margins: bool = False, use_graph: bool = True):
-        """Greedy decode from [B,S0,D] f32 embeddings with a KV cache (prefill + 1-token steps).  Same contract
+                        return_margins: bool = False, use_graph: bool = True, do_sample: bool = False,
+                        top_p: float = 1.0, temperature: float = 1.0, generator: Optional[torch.Generator] = None):
+        """Decode from [B,S0,D] f32 embeddings with a KV cache (prefill + 1-token steps).  Same contract
         as the oracle's greedy_generate: stop when ROW 0 ends with a stop sequence (conversation.py:102-107),
         EOS banned while fewer than `min_length` tokens were generated, finished rows padded with EOS.
         The single-token step is launch-bound (~420 kernels per token), so after one eager step it is captured
-        into a hipGraph and replayed: position / valid-length counters live in device memory."""
+        into a hipGraph and replayed: position / valid-length counters live in device memory.
+
+        `do_sample=True, top_p, temperature` are the eval script's arguments (evaluation_aqa_dataset.py:289-301).  HF's
+        top-p warper keeps the smallest descending-probability set whose mass reaches top_p (at least one token), so a
+        step whose p_max >= top_p IS the arg-max; the kernel reports p_max per row and only a row below the threshold is
+        drawn on the host from that row's logits (a genuine sample: reproducible here through `generator`, never
+        bit-comparable with another framework's RNG).  `last_generate_stats` counts such steps."""
         B, S0, D = inputs_embeds.shape
         T = S0 + max_new_tokens
         scale = 1.0 / math.sqrt(self.hd)
         caches = [torch.zeros((B, T, 2 * self.D), dtype=BF16, device=self.dev) for _ in self.layers]
         out_ids, margins = [], []
         unfinished = torch.ones(B, dtype=torch.long)
+        inv_temp = 1.0 / float(temperature) if do_sample else 1.0
+        stats = dict(steps=0, sampled_rows=0, min_pmax=1.0)
+        self.last_generate_stats = stats
         if self.lora is not None:
             self.lora.refresh(self.layers)
         if self.pack_decode and B <= 16:
@@ -303,14 +314,40 @@ class LlamaHIP:
         else:
             self._packed = None
 
-        def finish(logits, step):
-            ban = eos_id if step < min_length else -1
-            return ops.argmax_rows(logits, ban_id=ban, want_margin=True)
+        nxt_out = torch.empty((B,), dtype=torch.long, device=self.dev)
+        mar_out = torch.empty((B,), dtype=F32, device=self.dev)
+        pmx_out = torch.empty((B,), dtype=F32, device=self.dev)
+        logits_ref = [None]
 
-        def record(nxt_d, mar_d):
+        def pick(logits, ban):
+            logits_ref[0] = logits
+            ops.argmax_pmax_rows(logits, nxt_out, mar_out, pmx_out, ban_id=ban, inv_temp=inv_temp)
+
+        def sample_row(row: int, ban: int) -> int:
+            """HF TopPLogitsWarper + multinomial on one row (host)."""
+            lg = logits_ref[0][row].float().cpu() * inv_temp
+            if ban >= 0:
+                lg[ban] = float("-inf")
+            srt, idx = torch.sort(lg, descending=False)
+            cum = srt.softmax(-1).cumsum(-1)
+            remove = cum <= (1.0 - top_p)
+            remove[-1:] = False                                      # min_tokens_to_keep = 1
+            srt = srt.masked_fill(remove, float("-inf"))
+            probs = torch.zeros_like(lg).scatter(0, idx, srt.softmax(-1))
+            return int(torch.multinomial(probs, 1, generator=generator))
+
+        def record(ban: int):
             nonlocal unfinished
-            nxt = nxt_d.cpu()
-            margins.append(mar_d.cpu())
+            nxt = nxt_out.cpu()
+            margins.append(mar_out.cpu())
+            stats["steps"] += 1
+            if do_sample:
+                pm = pmx_out.cpu()
+                stats["min_pmax"] = min(stats["min_pmax"], float(pm[unfinished.bool()].min()) if int(unfinished.sum()) else 1.0)
+                for row in range(B):
+                    if int(unfinished[row]) and float(pm[row]) < top_p:
+                        nxt[row] = sample_row(row, ban)
+                        stats["sampled_rows"] += 1
             nxt = nxt * unfinished + eos_id * (1 - unfinished)       # HF pads finished rows with pad(=eos)
             unfinished = unfinished * (nxt != eos_id).long()
             out_ids.append(nxt)
@@ -324,26 +361,26 @@ class LlamaHIP:
         h = self._decode_block(inputs_embeds.reshape(B * S0, D).contiguous(), B, S0, caches, scale, pos, past=0)
         last = h.view(B, S0, D)[:, -1].contiguous()
         logits = ops.gemm(ops.rmsnorm_fwd(last, self.norm, self.eps), self.lm_head, out_dtype=F32)
-        nxt_d, mar_d = finish(logits, 0)
-        done = record(nxt_d, mar_d)
+        ban0 = eos_id if 0 < min_length else -1
+        pick(logits, ban0)
+        done = record(ban0)
 
         # ---- single-token steps; device-resident counters
         pos_dev = torch.full((B,), S0, dtype=torch.int32, device=self.dev)        # position of the incoming token
         kvlen_dev = torch.full((B,), S0 + 1, dtype=torch.int32, device=self.dev)  # valid keys after the append
         ids_dev = torch.empty((B,), dtype=torch.long, device=self.dev)
         x_in = torch.empty((B, D), dtype=F32, device=self.dev)
-        nxt_out = torch.empty((B,), dtype=torch.long, device=self.dev)
-        mar_out = torch.empty((B,), dtype=F32, device=self.dev)
+        lg_buf = torch.empty((B, self.V), dtype=F32, device=self.dev)             # fixed address: the graph writes it
 
         def token_step(ban):
             ops.embed_gather(self.embed, ids_dev, x_in)
             hh = self._decode_block(x_in, B, 1, caches, scale, pos_dev, pos_dev=pos_dev, kvlen_dev=kvlen_dev)
             hn = ops.rmsnorm_fwd(hh, self.norm, self.eps)
             if self._packed is not None:
-                lg = ops.gemv_packed(hn, self._packed["lm_head"], out_dtype=F32)
+                ops.gemv_packed(hn, self._packed["lm_head"], out=lg_buf, out_dtype=F32)
             else:
-                lg = ops.gemm(hn, self.lm_head, out_dtype=F32)
-            ops.argmax_rows(lg, ban_id=ban, want_margin=True, out=nxt_out, margin_out=mar_out)
+                ops.gemm(hn, self.lm_head, out=lg_buf)
+            pick(lg_buf, ban)
             ops.add_i32_(pos_dev, 1)
             ops.add_i32_(kvlen_dev, 1)
 
@@ -361,7 +398,7 @@ class LlamaHIP:
                     graph = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(graph):
                         token_step(-1)
-            done = record(nxt_out, mar_out)
+            done = record(ban)
             step += 1
         ids = torch.stack(out_ids, 1)
         if return_margins:

@@ -60,6 +60,7 @@ class LoraQV:
         self.dev = torch.device(device)
         self.P, self.G = params, grads
         self.step_seed = 0
+        self.base_seed = 0          # run seed + rank (train.py:63-72): ranks and runs draw different dropout masks
         self._xext: Dict[Tuple[int, int], torch.Tensor] = {}
         self._ws = torch.empty((_lib.load().mh_lora_wgrad_ws_floats(D, 2 * r),), dtype=F32, device=self.dev)
         self._deferred, self._side, self._wgrad_ev = [], None, None
@@ -108,7 +109,8 @@ class LoraQV:
                        "mh_lora_refresh_border")
 
     def _seed(self, layer_idx: int) -> int:
-        return (self.step_seed * 1315423911 + layer_idx * 2654435761 + 12345) & 0x7FFFFFFFFFFFFFFF
+        return (self.base_seed * 0x9E3779B97F4A7C15 + self.step_seed * 1315423911 + layer_idx * 2654435761 + 12345) \
+            & 0x7FFFFFFFFFFFFFFF
 
     # ---- forward: border = s * dropout(x) A_qv^T ------------------------------------------------------------------
     def forward_border(self, layer_idx: int, x_ext: torch.Tensor, training: bool = True):

@@ -37,30 +37,63 @@ def uses_weight_decay(name: str, ndim: int) -> bool:
     return not (ndim < 2 or "bias" in name or "ln" in name or "bn" in name)
 
 
+MODULES = ("expert_adaptor", "VETokenizer", "VEInstructor", "llama_proj", "lora")
+
+
+def module_of(name: str) -> str:
+    """The top-level reference module a trainable parameter belongs to (the unit torch's AdamW skips when unused)."""
+    for m in MODULES[:4]:
+        if name.startswith(m + "."):
+            return m
+    if "lora_" in name:
+        return "lora"
+    raise KeyError(name)
+
+
 class ParamStore:
-    """All trainable parameters in ONE flat fp32 buffer (+ grad, Adam m, v): a single RCCL all-reduce and two
-    fused AdamW launches per step.  Layout: [weight-decay group | no-decay group], segments 16-byte aligned."""
+    """All trainable parameters in ONE flat fp32 buffer (+ grad, Adam m, v): a single RCCL all-reduce and a handful of
+    fused AdamW launches per step.  Layout: [weight-decay group | no-decay group | per-module use flags]; inside each
+    group the parameters of one reference module are contiguous, segments 16-byte aligned.
+
+    torch.optim.AdamW (runner_base.py:132-137) skips a parameter whose .grad is None: a module that no rank used in a
+    step (VEInstructor at prompt stage 0, VETokenizer at stage 2; myriad.py:378,252,265) keeps its weights, moments and
+    step count.  Here every module has a device-resident use flag at the tail of the gradient buffer -- so the data-
+    parallel all-reduce sums it over ranks for free -- and a device-resident step counter; the gated AdamW kernel
+    (mh_adamw_gated) reads both, the host never synchronises."""
 
     def __init__(self, specs: List[Tuple[str, Tuple[int, ...], Tuple[int, ...]]], device):
         self.dev = torch.device(device)
-        wd = [s for s in specs if uses_weight_decay(s[0], len(s[2]))]
-        nwd = [s for s in specs if not uses_weight_decay(s[0], len(s[2]))]
+        order = {m: i for i, m in enumerate(MODULES)}
+        self.modules = [m for m in MODULES if any(module_of(s[0]) == m for s in specs)]
+        midx = {m: i for i, m in enumerate(self.modules)}
+        key = lambda s: order[module_of(s[0])]                    # stable: keeps each module's own order
+        wd = sorted([s for s in specs if uses_weight_decay(s[0], len(s[2]))], key=key)
+        nwd = sorted([s for s in specs if not uses_weight_decay(s[0], len(s[2]))], key=key)
         self.specs = wd + nwd
         self.offsets: Dict[str, Tuple[int, int]] = {}
+        self.ranges: List[Tuple[int, int, int, bool]] = []        # (module index, start, end, weight decay?)
         off = 0
-        for i, (name, ishape, _) in enumerate(self.specs):
-            if i == len(wd):
+        for group, decays in ((wd, True), (nwd, False)):
+            if not decays:
                 self.n_wd = off
-            n = 1
-            for s in ishape:
-                n *= s
-            self.offsets[name] = (off, n)
-            off += ops.round_up(n, 4)
-        if not nwd:
-            self.n_wd = off
+            for name, ishape, _ in group:
+                n = 1
+                for sdim in ishape:
+                    n *= sdim
+                self.offsets[name] = (off, n)
+                mi = midx[module_of(name)]
+                if self.ranges and self.ranges[-1][0] == mi and self.ranges[-1][3] == decays:
+                    self.ranges[-1] = (mi, self.ranges[-1][1], off + ops.round_up(n, 4), decays)
+                else:
+                    self.ranges.append((mi, off, off + ops.round_up(n, 4), decays))
+                off += ops.round_up(n, 4)
         self.total = off
+        nm = len(self.modules)
         self.flat_p = torch.zeros(off, dtype=F32, device=self.dev)
-        self.flat_g = torch.zeros(off, dtype=F32, device=self.dev)
+        self.flat_g_comm = torch.zeros(off + ops.round_up(max(nm, 1), 4), dtype=F32, device=self.dev)   # what DP exchanges
+        self.flat_g = self.flat_g_comm[:off]
+        self.used = self.flat_g_comm[off:off + nm]                # per-module use count (summed over ranks by the all-reduce)
+        self.steps_dev = torch.zeros(max(nm, 1), dtype=torch.int32, device=self.dev)
         self.flat_m = torch.zeros(off, dtype=F32, device=self.dev)
         self.flat_v = torch.zeros(off, dtype=F32, device=self.dev)
         self.p, self.g = {}, {}
@@ -70,21 +103,60 @@ class ParamStore:
             self.p[name] = self.flat_p[o:o + n].view(ishape)
             self.g[name] = self.flat_g[o:o + n].view(ishape)
             self.ref_shape[name] = rshape
-        self.step = 0
+        self.step = 0                                             # optimiser calls so far (host)
 
     def n_params(self) -> int:
         return sum(n for _, n in self.offsets.values())
 
+    def mark_used(self, used_modules) -> None:
+        """Write this rank's use flags (1.0 per used module) into the tail of the gradient buffer."""
+        if not self.modules:
+            return
+        flags = torch.tensor([1.0 if m in used_modules else 0.0 for m in self.modules], dtype=F32)
+        self.used.copy_(ops.h2d(flags, self.dev))
+
+    def module_steps(self) -> Dict[str, int]:
+        """Updates applied per module so far (device -> host: checkpointing only)."""
+        st = self.steps_dev.cpu().tolist()
+        return {m: int(st[i]) for i, m in enumerate(self.modules)}
+
+    def set_module_steps(self, steps: Dict[str, int]) -> None:
+        host = torch.tensor([int(steps.get(m, 0)) for m in self.modules] or [0], dtype=torch.int32)
+        self.steps_dev.copy_(host.to(self.dev))
+
     def adamw_step(self, lr: float, weight_decay: float = 0.05, beta2: float = 0.999, grad_scale: float = 1.0):
-        """torch.optim.AdamW semantics (runner_base.py:132-137), fused, on the flat buffers."""
+        """torch.optim.AdamW semantics (runner_base.py:132-137), fused, on the flat buffers; modules unused on every rank
+        this step are left alone (see class docstring)."""
         self.step += 1
-        a = self.n_wd
-        if a > 0:
-            ops.adamw_step(self.flat_p[:a], self.flat_g[:a], self.flat_m[:a], self.flat_v[:a], lr, weight_decay,
-                           self.step, beta2=beta2, grad_scale=grad_scale)
-        if self.total > a:
-            ops.adamw_step(self.flat_p[a:], self.flat_g[a:], self.flat_m[a:], self.flat_v[a:], lr, 0.0, self.step,
-                           beta2=beta2, grad_scale=grad_scale)
+        for mi, a, b, decays in self.ranges:
+            ops.adamw_gated(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b], lr,
+                            weight_decay if decays else 0.0, self.used[mi:mi + 1], self.steps_dev[mi:mi + 1], beta2=beta2,
+                            grad_scale=grad_scale)
+        if self.modules:
+            ops.adamw_bump(self.used, self.steps_dev)
+
+
+def init_trainable(name: str, rshape) -> torch.Tensor:
+    """Fresh trainable parameter, drawn from torch's global CPU RNG with the distribution the reference's constructor uses:
+    LoraAdaptorV2 N(0, 0.02) (networks.py:78-79), nn.Conv2d default (kaiming-uniform, a = sqrt(5): U(+-1/sqrt(fan_in)) for
+    weight and bias, networks.py:98-127,159-189), base_prompts N(0, 1) (:189).  llama_proj (MiniGPT-4 stage 2) is an
+    nn.Linear whose reset_parameters the reference disables (common/utils.py:41-47): it must come from a checkpoint."""
+    import math
+    if name.startswith("expert_adaptor."):
+        return torch.randn(rshape) * 0.02
+    if name.endswith("base_prompts"):
+        return torch.randn(rshape)
+    if ".meta_net." in name:
+        if name.endswith(".weight"):
+            fan_in = rshape[1] * rshape[2] * rshape[3]
+        else:                                   # bias bound uses the layer's fan-in: recover it from the stack's geometry
+            idx = int(name.split(".meta_net.")[1].split(".")[0])
+            cin = {0: 1, 3: 4, 6: 16, 9: 64, 12: 256, 15: 1024}[idx]
+            k = 3 if idx < 15 else (5 if name.startswith("VETokenizer.") else 1)
+            fan_in = cin * k * k
+        bound = 1.0 / math.sqrt(fan_in)
+        return (torch.rand(rshape) * 2 - 1) * bound
+    raise KeyError(f"{name}: not in the weight files and no constructor init exists (load it with `ckpt`)")
 
 
 class _LossBridge(torch.autograd.Function):
@@ -98,7 +170,10 @@ class _LossBridge(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, gout):
-        ctx.model.backward(float(gout))
+        # gout is the scalar the caller back-propagates (1.0, or the GradScaler's loss scale under amp=True,
+        # base_task.py:256-259): the gradients are multiplied by it so that scaler.unscale_() / step() see what they expect.
+        # The read-back is a host sync per step, like the reference's own loss.item() (base_task.py:276).
+        ctx.model.backward(float(gout), accumulate=ctx.model._grads_live())
         return None, None, None
 
 
@@ -123,7 +198,8 @@ class MyriadHIP(nn.Module):
         self.visual_encoder = EvaViTHIP(weights, cfg.get("vit_heads", 16), self._dev)
         self.qformer = QFormerHIP(weights, cfg.get("qf_heads", 12), self._dev,
                                   need_backward=need_bwd and self.arch == "myriad")
-        self.llama = LlamaHIP(weights, cfg.get("llm_heads", 32), self._dev, need_backward=need_bwd)
+        self.llama = LlamaHIP(weights, cfg.get("llm_heads", 32), self._dev, eps=float(cfg.get("llm_eps", 1e-6)),
+                              need_backward=need_bwd)
         self.ln_w = weights["ln_vision.weight"].to(self._dev, F32).contiguous()
         self.ln_b = weights["ln_vision.bias"].to(self._dev, F32).contiguous()
         self.query_tokens_f32 = weights["query_tokens"].to(self._dev, F32).contiguous()      # frozen (myriad.py:165)
@@ -157,8 +233,10 @@ class MyriadHIP(nn.Module):
         for name, ishape, rshape in self.store.specs:
             if name in lora_init and name not in weights:
                 src = lora_init[name]
-            else:
+            elif name in weights:
                 src = weights[name]
+            else:
+                src = init_trainable(name, rshape)      # built from the frozen files only: the reference's constructors' init
             self.store.p[name].copy_(from_reference_layout(src.to(self._dev, F32), ishape))
             prm = nn.Parameter(self.store.p[name], requires_grad=True)
             prm.grad = self.store.g[name]
@@ -178,6 +256,7 @@ class MyriadHIP(nn.Module):
         self._leaf_aside = os.environ.get("MYRIAD_LEAF_STREAM", "1") != "0"
         self._anchor = torch.zeros((), device=self._dev, requires_grad=True)
         self._ctx = None
+        self._has_grads, self._bwd_gscale, self._bwd_prev = False, 1.0, None
 
     # ------------------------------------------------------------------ nn.Module plumbing
     def _register_dotted(self, name: str, prm: nn.Parameter):
@@ -195,8 +274,10 @@ class MyriadHIP(nn.Module):
 
     def to(self, *args, **kwargs):   # the model is built in place on its device
         dev = args[0] if args else kwargs.get("device", self._dev)
-        if isinstance(dev, (str, torch.device)) and torch.device(dev).type != self._dev.type:
-            raise RuntimeError(f"{type(self).__name__} lives on {self._dev}; build it there (no CPU path exists)")
+        if isinstance(dev, (str, torch.device)):
+            d = torch.device(dev)
+            if d.type != self._dev.type or (d.index is not None and d.index != self._dev.index):
+                raise RuntimeError(f"{type(self).__name__} lives on {self._dev}; build it there (cfg.device; no CPU path exists)")
         return self
 
     def before_evaluation(self, **kwargs):   # base_model.py:102-103
@@ -223,19 +304,50 @@ class MyriadHIP(nn.Module):
 
     @classmethod
     def from_config(cls, cfg):
-        """`Myriad.from_config` (myriad.py:456-517).  cfg['weights'] is a mapping keyed by the reference's
-        state_dict names (a loaded checkpoint dict or myriad_amd.synthetic.SyntheticWeights)."""
+        """`Myriad.from_config` / `MiniGPT4.from_config` (myriad.py:456-517, mini_gpt4.py:259-307) with the reference's own
+        keys: vit_model, q_former_model, image_size, num_query_token, llama_model, drop_path_rate, use_grad_checkpoint,
+        vit_precision, freeze_vit, freeze_qformer, freeze_llama, use_lora, k_shot, round_index, prompt_path,
+        prompt_template, max_txt_len, end_sym, low_resource, device_8bit, ckpt.  The frozen weights and the tokenizer are
+        loaded from the files those keys name (checkpoint.load_reference_weights); `cfg["weights"]` / `cfg["tokenizer"]`
+        (an in-memory mapping keyed by the reference's state_dict names, e.g. synthetic.SyntheticWeights) replace the
+        files in tests and in bench.py."""
         get = cfg.get if hasattr(cfg, "get") else (lambda k, d=None: getattr(cfg, k, d))
+        if get("low_resource", False):
+            raise NotImplementedError("low_resource (8-bit LLaMA + ViT on the CPU, myriad.py:186-192) is not part of the MI355X path")
+        for k in ("freeze_vit", "freeze_qformer", "freeze_llama"):
+            if get(k, True) is False:
+                raise NotImplementedError(f"{k}: False -- the HIP path keeps ViT / Q-Former / LLaMA frozen (dgrad only), as every "
+                                          "shipped recipe does (train_configs/*.yaml)")
+        if get("drop_path_rate", 0) or get("use_grad_checkpoint", False):
+            raise NotImplementedError("drop_path_rate / use_grad_checkpoint only matter for an unfrozen ViT")
+        keys = ("max_txt_len", "end_sym", "k_shot", "round_index", "fixed_stage", "fixed_taskstage", "tokenizer",
+                "vit_heads", "qf_heads", "llm_heads", "need_backward", "bos_token_id", "pad_token_id", "use_lora",
+                "lora_r", "lora_alpha", "lora_dropout", "lora_seed", "num_query_token", "llm_eps")
+        sub = {k: get(k) for k in keys if get(k) is not None}
+        if get("max_txt_len") is None:
+            sub["max_txt_len"] = 32                       # from_config defaults (myriad.py:483-484)
+        if get("end_sym") is None:
+            sub["end_sym"] = "\n"
         weights = get("weights")
         if weights is None:
-            raise ValueError("cfg['weights'] is required (checkpoint state dict or SyntheticWeights)")
-        keys = ("max_txt_len", "end_sym", "k_shot", "fixed_stage", "fixed_taskstage", "tokenizer", "prompt_list",
-                "vit_heads", "qf_heads", "llm_heads", "need_backward", "bos_token_id", "pad_token_id", "use_lora",
-                "lora_r", "lora_alpha", "lora_dropout", "lora_seed")
-        sub = {k: get(k) for k in keys if get(k) is not None}
-        model = cls(weights, sub, device=get("device", "cuda:0"))
+            from .checkpoint import load_llama_tokenizer, load_reference_weights
+            weights, meta = load_reference_weights(cfg, arch=cls.arch)
+            for k, v in meta.items():
+                sub.setdefault(k, v)
+            if "tokenizer" not in sub:
+                sub["tokenizer"] = load_llama_tokenizer(get("llama_model"))
+        prompt_path, template = get("prompt_path", ""), get("prompt_template", "")
+        if prompt_path:                                   # myriad.py:221-231
+            with open(prompt_path, "r") as f:
+                raw = f.read().splitlines()
+            sub["prompt_list"] = [template.format(p_) for p_ in raw if "<ImageHere>" in p_]
+        dev = get("device")
+        if dev is None or dev == "cuda":
+            dev = f"cuda:{torch.cuda.current_device()}" if torch.cuda.is_available() else "cuda:0"
+        model = cls(weights, sub, device=dev)
         ckpt = get("ckpt", "")
         if ckpt:
+            print("Load BLIP2-LLM Checkpoint: {}".format(ckpt))
             model.load_state_dict(torch.load(ckpt, map_location="cpu")["model"], strict=False)
         return model
 
@@ -371,7 +483,8 @@ class MyriadHIP(nn.Module):
         before, after, tgt, tmask = self._tokenize(samples, image.shape[0], stage, True)
         parts = self.encode_img(image, maps, stage, need_grad, vit_out=vit_out)
         emb, attn, labels, img_slices = self._assemble(parts, before, after, tgt, tmask)
-        loss = self.llama.forward_loss(emb, attn, labels, save_for_backward=need_grad)
+        loss = self.llama.forward_loss(emb, attn, labels, save_for_backward=need_grad,
+                                       lora_training=need_grad and self.training)   # peft's Dropout is off in eval()
         if need_grad:
             self._ctx["img_slices"] = img_slices
         return loss
@@ -385,15 +498,32 @@ class MyriadHIP(nn.Module):
             return {"loss": _LossBridge.apply(self._anchor, self, loss)}
         return {"loss": loss}
 
-    def backward(self, gscale: float = 1.0):
-        """Explicit backward of the last forward: fills the flat gradient buffer (unused modules -> zeros,
-        the DDP find_unused_parameters semantics of runner_base.py:96-98)."""
+    def _grads_live(self) -> bool:
+        """True when gradients of an earlier backward are still attached (no optimizer.zero_grad() since): the reference
+        loop accumulates over `accum_grad_iters` backward calls before it steps (base_task.py:256-271)."""
+        return self._has_grads and any(prm.grad is not None for prm in self._params.values())
+
+    def backward(self, gscale: float = 1.0, accumulate: bool = False):
+        """Explicit backward of the last forward: fills the flat gradient buffer, multiplied by `gscale` (a GradScaler's
+        loss scale; 1.0 otherwise).  Modules this step did not use keep zero gradients AND a zero use flag, so the gated
+        AdamW leaves them untouched unless another rank used them (ParamStore).  With `accumulate` the result is added to
+        the gradients already in the buffer."""
         c = self._ctx
         if c is None:
             raise RuntimeError("backward() without a training forward")
-        if gscale != 1.0:
-            raise NotImplementedError("bf16 path needs no loss scaling")
-        self.store.flat_g.zero_()
+        prev = self.store.flat_g_comm.clone() if accumulate else None
+        self.store.flat_g_comm.zero_()
+        used = {"lora"} if self.use_lora else set()
+        if self.arch == "myriad":
+            used.add("expert_adaptor")
+            if c["use_tok"]:
+                used.add("VETokenizer")
+            if c["use_ins"]:
+                used.add("VEInstructor")
+        else:
+            used.add("llama_proj")
+        self.store.mark_used(used)
+        self._bwd_gscale, self._bwd_prev = float(gscale), prev
         demb = self.llama.backward(defer_lora_join=True)              # [B,S,Dl] f32; LoRA wgrads run on a side stream
         B, nq = c["B"], c["nq"]
         (c0, n0) = c["img_slices"][0]
@@ -407,8 +537,7 @@ class MyriadHIP(nn.Module):
             self.store.g["llama_proj.bias"].copy_(ops.colsum(dimg.view(B * nq, self.Dl)))
             if self.llama.lora is not None:
                 self.llama.lora.join_wgrads()
-            self._reattach_grads()
-            self._ctx = None
+            self._finish_backward()
             return
         dqo = ops.gemm(dimg_b, self.proj_wT, out_dtype=F32).view(B, nq, self.Dq)
         if c["use_tok"]:
@@ -441,6 +570,16 @@ class MyriadHIP(nn.Module):
         if leaf_ev is not None:
             torch.cuda.current_stream().wait_event(leaf_ev)
         del leaf_keep                                     # freed only now: later main-stream work is ordered behind the event
+        self._finish_backward()
+
+    def _finish_backward(self):
+        if self._bwd_gscale != 1.0:
+            ops.scale_(self.store.flat_g, self._bwd_gscale)
+        if self._bwd_prev is not None:
+            n = self.store.flat_g_comm.numel()
+            ops.copy2d(self._bwd_prev.view(1, n), self.store.flat_g_comm.view(1, n), accumulate=True)
+            self._bwd_prev = None
+        self._has_grads = True
         self._reattach_grads()
         self._ctx = None
 
@@ -498,13 +637,13 @@ class MyriadHIP(nn.Module):
             loss = self._forward_impl(samples, True, vit_out=vit_out)
             self.backward()
             if dp is not None and dp.world > 1 and overlap:
-                dp.start(self.store.flat_g)                       # RCCL all-reduce(sum) on the side HIP stream
+                dp.start(self.store.flat_g_comm)                  # RCCL all-reduce(sum) on the side HIP stream (grads + use flags)
                 self._pending_update = (dp, lr, weight_decay)
             else:
                 if dp is not None and dp.world > 1:
-                    dp.allreduce(self.store.flat_g)
+                    dp.allreduce(self.store.flat_g_comm)
                 elif allreduce is not None:
-                    allreduce(self.store.flat_g)
+                    allreduce(self.store.flat_g_comm)
                     world = max(world, 1)
                 self.store.adamw_step(lr, weight_decay, grad_scale=1.0 / (dp.world if dp is not None else world))
         return loss
@@ -519,8 +658,39 @@ class MyriadHIP(nn.Module):
 
     @torch.no_grad()
     def generate(self, samples, **generate_kwargs):
-        """`Myriad.generate` (myriad.py:433-454): stage 1 prompt layout, greedy decode (top_p=0.01 sampling of
-        evaluation_aqa_dataset.py:289-301 restated as arg-max), stop criterion on row 0."""
+        """`Myriad.generate` (myriad.py:433-454): stage-1 prompt layout, then the HF `generate(inputs_embeds=..., **kw)`
+        contract for the arguments the evaluation script passes (evaluation_aqa_dataset.py:289-301):
+        max_new_tokens, stopping_criteria (a list whose items carry `.stops` = id tensors, conversation.py:96-107, applied
+        to batch row 0), do_sample + top_p + temperature (see LlamaHIP.greedy_generate: arg-max whenever p_max >= top_p,
+        a host-side draw otherwise), min_length, use_cache.  Anything that would change the decoding rule and is not
+        implemented raises instead of being ignored."""
+        kw = dict(generate_kwargs)
+        stops = kw.pop("stop_ids", None)
+        crit = kw.pop("stopping_criteria", None)
+        if crit is not None:
+            stops = [tuple(int(t) for t in torch.as_tensor(st).reshape(-1).tolist()) for c in crit for st in getattr(c, "stops", [])]
+        if stops is None:
+            stops = ()                                     # HF without a criterion stops on EOS / max_new_tokens only
+        max_new = kw.pop("max_new_tokens", None)
+        if max_new is None:
+            max_len = kw.pop("max_length", None)
+            max_new = 20 if max_len is None else None
+        do_sample = bool(kw.pop("do_sample", False))
+        top_p = float(kw.pop("top_p", 1.0))
+        temperature = float(kw.pop("temperature", 1.0))
+        min_length = int(kw.pop("min_length", 0))
+        eos_id = kw.pop("eos_token_id", self.pad_id)
+        kw.pop("pad_token_id", None)
+        if not kw.pop("use_cache", True):
+            raise NotImplementedError("use_cache=False: decode here always keeps a KV cache (same tokens)")
+        for k, neutral in (("num_beams", 1), ("repetition_penalty", 1.0), ("length_penalty", 1), ("top_k", 0),
+                           ("num_return_sequences", 1)):
+            v = kw.pop(k, neutral)
+            if v not in (neutral, None) and not (k == "top_k" and not do_sample):
+                raise NotImplementedError(f"generate({k}={v}) is not implemented on the HIP decode path")
+        generator = kw.pop("generator", None)
+        if kw:
+            raise TypeError(f"generate() got unsupported arguments: {sorted(kw)}")
         stage = 1 if self.arch == "myriad" else 0
         image = samples["image"].to(self._dev, F32)
         maps = None
@@ -531,11 +701,27 @@ class MyriadHIP(nn.Module):
         parts = self.encode_img(image, maps, stage, False)
         emb, _, _, _ = self._assemble(parts, before, after, None, None)
         emb = emb[:, 1:].contiguous()         # generate() wraps without BOS (myriad.py:446-449)
-        stops = generate_kwargs.get("stop_ids", ((835,), (2277, 29937)))
-        ids = self.llama.greedy_generate(emb, max_new_tokens=generate_kwargs.get("max_new_tokens", 90),
-                                         stop_ids=stops, min_length=generate_kwargs.get("min_length", 1),
-                                         eos_id=generate_kwargs.get("eos_token_id", 2))
+        if max_new is None:
+            max_new = max(1, max_len - emb.shape[1])
+        ids = self.llama.greedy_generate(emb, max_new_tokens=max_new, stop_ids=stops, min_length=min_length, eos_id=eos_id,
+                                         do_sample=do_sample, top_p=top_p, temperature=temperature, generator=generator)
+        self.last_generate_stats = self.llama.last_generate_stats
         return {"token_ids": ids, "ve_anomaly_maps": maps}
+
+
+class StoppingCriteriaSub:
+    """`StoppingCriteriaSub` (conversation.py:96-107) for callers that build the criterion themselves: holds `stops`, and
+    `__call__(input_ids, scores)` is the reference's row-0 suffix test.  `generate()` reads `.stops`."""
+
+    def __init__(self, stops=(), encounters=1):
+        self.stops = list(stops)
+
+    def __call__(self, input_ids, scores=None):
+        for stop in self.stops:
+            stop = torch.as_tensor(stop).to(input_ids.device)
+            if torch.all((stop == input_ids[0][-len(stop):])).item():
+                return True
+        return False
 
 
 class MiniGPT4HIP(MyriadHIP):

@@ -601,6 +601,14 @@ def argmax_rows(logits: torch.Tensor, ban_id: int = -1, want_margin: bool = Fals
     return (out, margin) if want_margin else out
 
 
+def argmax_pmax_rows(logits: torch.Tensor, out, margin_out, pmax_out, ban_id: int = -1, inv_temp: float = 1.0):
+    """Row arg-max + top-1/top-2 margin + p_max = softmax(logits * inv_temp)[argmax] into the given buffers."""
+    R, V = logits.shape
+    _lib.check(_L().mh_argmax_pmax_rows(_p(logits), logits.stride(0), _p(out), _p(margin_out), _p(pmax_out), R, V, ban_id,
+                                        float(inv_temp), _s()), "mh_argmax_pmax_rows")
+    return out, margin_out, pmax_out
+
+
 # --------------------------------------------------------------------------- conv stack pieces
 def im2col(x_nhwc: torch.Tensor, kh: int, kw: int, pad: int):
     B, H, W, C = x_nhwc.shape
@@ -653,6 +661,16 @@ def adamw_step(p, g, m, v, lr, wd, step, beta1=0.9, beta2=0.999, eps=1e-8, grad_
     _lib.check(_L().mh_adamw_step(_p(p), _p(g), _p(m), _p(v), _p(shadow), p.numel(), float(lr), float(beta1),
                                   float(beta2), float(eps), float(wd), int(step), float(grad_scale), _s()),
                "mh_adamw_step")
+
+
+def adamw_gated(p, g, m, v, lr, wd, used: torch.Tensor, steps: torch.Tensor, beta1=0.9, beta2=0.999, eps=1e-8, grad_scale=1.0):
+    """AdamW on one contiguous range iff the device scalar `used` > 0, with step = device scalar `steps` + 1."""
+    _lib.check(_L().mh_adamw_gated(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps),
+                                   float(wd), float(grad_scale), _p(used), _p(steps), _s()), "mh_adamw_gated")
+
+
+def adamw_bump(used: torch.Tensor, steps: torch.Tensor):
+    _lib.check(_L().mh_adamw_bump(_p(used), _p(steps), steps.numel(), _s()), "mh_adamw_bump")
 
 
 # --------------------------------------------------------------------------- vision-expert map heads (K16)

@@ -11,6 +11,7 @@ is zero-filled each backward), which is exactly DDP's find_unused_parameters sem
 """
 from __future__ import annotations
 
+import json
 import math
 import os
 import random
@@ -144,3 +145,177 @@ def train_loop(model, data_iter: Callable[[], dict], n_steps: int, scheduler: Li
         samples = nxt if nxt is not None else (data_iter() if i + 1 < n_steps else None)
     model.finish_update()                # flush the delayed (overlapped) optimiser update of the last step
     return losses
+
+
+# ------------------------------------------------------------------------------------------------ the runner
+class IterLoader:
+    """`IterLoader` (datasets/datasets/dataloader_utils.py:145-181): endless iterator over a DataLoader that bumps the
+    DistributedSampler's epoch at every wrap-around."""
+
+    def __init__(self, loader, use_distributed: bool = False):
+        self.loader, self.use_distributed = loader, use_distributed
+        self._it, self.epoch = None, 0
+
+    def __iter__(self):
+        return self
+
+    def __len__(self):
+        return len(self.loader)
+
+    def __next__(self):
+        if self._it is None:
+            self._it = iter(self.loader)
+        try:
+            return next(self._it)
+        except StopIteration:
+            self.epoch += 1
+            if hasattr(self.loader, "sampler") and hasattr(self.loader.sampler, "set_epoch") and self.use_distributed:
+                self.loader.sampler.set_epoch(self.epoch)
+            self._it = iter(self.loader)
+            return next(self._it)
+
+
+class SmoothedValue:
+    """`SmoothedValue` (common/logger.py:19-74) reduced to what the train log prints: last value and global average."""
+
+    def __init__(self):
+        self.total, self.count, self.value = 0.0, 0, 0.0
+
+    def update(self, v: float):
+        self.value = float(v)
+        self.total += float(v)
+        self.count += 1
+
+    @property
+    def global_avg(self) -> float:
+        return self.total / max(self.count, 1)
+
+
+class RunnerBase:
+    """`RunnerBase` (runners/runner_base.py:42-686) for the HIP model: device / distributed setup, loaders
+    (DistributedSampler; the AnomalyDetection loader yields batch_size_train // 2 samples which the model doubles with
+    their augmented copies, :546-549), the epoch loop with resume (:374-432), the step loop of
+    `BaseTask._train_inner_loop` (base_task.py:202-294), `checkpoint_N.pth` after every epoch (:592-628) and the JSON-lines
+    `log.txt` (:674-686).  The optimiser is the model's fused AdamW on the flat buffer; data parallelism is
+    `DataParallel` (one RCCL all-reduce per step on a side stream) instead of a DDP wrapper."""
+
+    def __init__(self, cfg, job_id: str, model, datasets: dict, rank: int = 0, world: int = 1, device=None):
+        self.config, self.job_id, self._model, self.datasets = cfg, job_id, model, datasets
+        self.rank, self.world = rank, world
+        self.device = torch.device(device if device is not None else getattr(model, "device", "cuda"))
+        run = cfg.run_cfg
+        self.max_epoch = int(run.get("max_epoch", 1))
+        self.start_epoch = 0
+        self.log_freq = int(run.get("log_freq", 50))
+        self.resume_ckpt_path = run.get("resume_ckpt_path", None)
+        self.evaluate_only = bool(run.get("evaluate", False))
+        self.accum_grad_iters = int(run.get("accum_grad_iters", 1))
+        if self.accum_grad_iters != 1:
+            raise NotImplementedError("accum_grad_iters > 1: use model(samples)['loss'].backward() with your own optimiser "
+                                      "(the autograd bridge accumulates); the fused train_step path steps every iteration")
+        out_root = run.get("output_dir", "output")
+        self.output_dir = os.path.join(out_root, job_id)
+        if self.rank == 0:
+            os.makedirs(self.output_dir, exist_ok=True)
+        from .checkpoint import CheckpointManager
+        self.ckpt = CheckpointManager(self.output_dir, max_checkpoints=int(run.get("max_checkpoints", 1)))
+        self.dp = DataParallel(device=self.device) if world > 1 else None
+        self._sched, self._loader = None, None
+
+    # ---- properties mirroring the reference's lazily built members
+    @property
+    def model(self):
+        return self._model
+
+    @property
+    def lr_scheduler(self):
+        if self._sched is None:
+            run = self.config.run_cfg
+            cls = registry.get_lr_scheduler_class(run.get("lr_sched", "linear_warmup_cosine_lr"))
+            if cls is None:
+                raise KeyError(f"lr_sched '{run.get('lr_sched')}' is not registered")
+            ipe = run.get("iters_per_epoch", None)
+            if ipe is None:
+                ipe = len(self.train_loader.loader) if hasattr(self.train_loader, "loader") else 10000
+            self._sched = cls(optimizer=None, max_epoch=self.max_epoch, iters_per_epoch=int(ipe), min_lr=float(run.get("min_lr", 0)),
+                              init_lr=float(run.get("init_lr", 1e-4)), warmup_start_lr=float(run.get("warmup_lr", -1)),
+                              warmup_steps=int(run.get("warmup_steps", 0)))
+        return self._sched
+
+    @property
+    def train_loader(self):
+        if self._loader is None:
+            from torch.utils.data import DataLoader
+            from torch.utils.data.distributed import DistributedSampler
+            from .datasets import collate
+            run = self.config.run_cfg
+            names = list(self.datasets)
+            if len(names) != 1:
+                raise NotImplementedError("one training dataset per run (the shipped recipes use one)")
+            ds = self.datasets[names[0]]
+            bsz = int(run.get("batch_size_train", 4))
+            if getattr(ds, "DatasetName", "") == "AnomalyDetection":
+                bsz = max(1, bsz // 2)                       # runner_base.py:546-549
+            sampler = DistributedSampler(ds, shuffle=True, num_replicas=self.world, rank=self.rank) if self.world > 1 else None
+            loader = DataLoader(ds, batch_size=bsz, num_workers=int(run.get("num_workers", 0)), pin_memory=False, sampler=sampler,
+                                shuffle=sampler is None, collate_fn=collate, drop_last=True)
+            self._loader = IterLoader(loader, use_distributed=self.world > 1)
+        return self._loader
+
+    # ---- logging
+    def log_stats(self, stats: dict, split_name: str):
+        if self.rank != 0:
+            return
+        with open(os.path.join(self.output_dir, "log.txt"), "a") as f:
+            f.write(json.dumps({f"{split_name}_{k}": v for k, v in stats.items()}) + "\n")
+
+    def log_config(self):
+        if self.rank != 0:
+            return
+        with open(os.path.join(self.output_dir, "log.txt"), "a") as f:
+            f.write(json.dumps(self.config.to_dict(), indent=4) + "\n")
+
+    # ---- training
+    def train_epoch(self, epoch: int) -> dict:
+        run = self.config.run_cfg
+        model, sched, loader = self.model, self.lr_scheduler, self.train_loader
+        model.train()
+        iters = int(run.get("iters_per_epoch", len(loader)))
+        wd = float(run.get("weight_decay", 0.05))
+        meters = {"lr": SmoothedValue(), "loss": SmoothedValue()}
+        samples = next(loader) if iters > 0 else None
+        for i in range(iters):
+            samples.update({"epoch": epoch, "num_iters_per_epoch": iters, "iters": i})      # base_task.py:217-223
+            lr = sched.step(cur_epoch=epoch, cur_step=i)                                    # stepped BEFORE the forward (:229)
+            nxt = next(loader) if i + 1 < iters else None                                   # one batch of lookahead: its frozen
+            loss = model.train_step(samples, lr, wd, dp=self.dp, next_samples=nxt)          # ViT forward runs on a side stream
+            meters["loss"].update(float(loss))                                              # loss.item() per step (:276)
+            meters["lr"].update(lr)
+            if self.rank == 0 and (i % self.log_freq == 0 or i == iters - 1):
+                print(f"Train: data epoch: [{epoch}]  [{i}/{iters}]  lr: {lr:.6f}  loss: {meters['loss'].value:.4f}", flush=True)
+            samples = nxt
+        model.finish_update()
+        if self.dp is not None:                                                             # logger.py:43-48 cross-rank average
+            t = torch.tensor([meters["loss"].count, meters["loss"].total], dtype=torch.float64, device=self.device)
+            self.dp.dist.all_reduce(t)
+            meters["loss"].count, meters["loss"].total = int(t[0].item()), float(t[1].item())
+        return {k: "{:.3f}".format(m.global_avg) for k, m in meters.items()}
+
+    def train(self):
+        self.log_config()
+        if not self.evaluate_only and self.resume_ckpt_path:
+            self.start_epoch = self.ckpt.load(self.model, self.resume_ckpt_path)
+        cur_epoch = self.start_epoch
+        for cur_epoch in range(self.start_epoch, self.max_epoch):
+            if not self.evaluate_only:
+                stats = self.train_epoch(cur_epoch)
+                self.log_stats(stats, "train")
+                if self.rank == 0:                             # no validation split in the shipped recipes: save every epoch
+                    lr = self.lr_scheduler.lr_at(cur_epoch, int(self.config.run_cfg.get("iters_per_epoch", 1)) - 1)
+                    self.ckpt.save(self.model, cur_epoch, lr, float(self.config.run_cfg.get("weight_decay", 0.05)),
+                                   config=self.config.to_dict())
+            if self.evaluate_only:
+                break
+            if self.dp is not None:
+                self.dp.barrier()
+        return cur_epoch

@@ -102,6 +102,55 @@ def llama_weights(D: int, layers: int, inter: int, vocab: int, seed: int, prefix
     return sd
 
 
+# ---- peaked-logit decode fixture (SURVEY 9.2: random-weight logits are flat; greedy ids are only comparable with margin)
+# The tiny LLaMA is made a token-transition machine: embeddings of the used tokens are scaled random directions that
+# dominate the residual stream, and lm_head[f(t)] carries the unit direction of embed[t], so the arg-max after token t is
+# f(t) with a margin of several logits whatever the two small decoder layers add.  The chains exercise, with the eval
+# script's real stop ids (evaluation_aqa_dataset.py:268-270): the min_length EOS ban on step 0 (row 0's favourite first
+# token is EOS), the two-token stop [2277, 29937] on row 0 after 32 tokens, a row that finishes early with EOS and is then
+# padded, and a row that emits 835 without stopping the batch (the criterion looks at row 0 only, conversation.py:102-107).
+DECODE_CHAIN = dict(D=64, layers=2, heads=4, inter=172, vocab=32000, seed=601, s0=6)
+DECODE_CHAINS = {
+    "row0": [100] + list(range(101, 131)) + [2277, 29937],                 # start token, then the expected generation
+    "row1": [200] + list(range(201, 246)),
+    "row2": [300, 301, 302, 303, 2],
+    "row3": [400, 401, 835, 402] + list(range(403, 440)),
+    "stop835": [500, 501, 502, 835],
+}
+
+
+def decode_chain_weights() -> Dict[str, torch.Tensor]:
+    c = DECODE_CHAIN
+    D, V = c["D"], c["vocab"]
+    sd = llama_weights(D, c["layers"], c["inter"], V, c["seed"], std=0.05)
+    g = torch.Generator().manual_seed(c["seed"] + 1)
+    emb = sd["llama_model.model.embed_tokens.weight"]
+    lm = sd["llama_model.lm_head.weight"]
+    used = sorted({t for ch in DECODE_CHAINS.values() for t in ch})
+    dirs = {}
+    for t in used:
+        v = torch.randn(D, generator=g)
+        dirs[t] = v / v.norm()
+        emb[t] = dirs[t] * math.sqrt(D) * 2.0
+    for name, ch in DECODE_CHAINS.items():
+        for a, b in zip(ch[:-1], ch[1:]):
+            lm[b] += 2.5 * dirs[a]      # logit ~ 20 against ~N(0, 1) for the other 32k rows: p_max ~ 1 (>= the eval's top_p 0.01)
+    lm[2] += 2.5 * dirs[100]        # row 0's favourite FIRST token is EOS: banned by min_length = 1, ...
+    lm[101] -= 0.75 * dirs[100]     # ... which leaves 101 (0.7 of the direction) as the clear runner-up
+    return sd
+
+
+def decode_chain_inputs(rows) -> torch.Tensor:
+    """[B, s0, D] prompt embeddings: small noise, last position = the embedding of the row's start token."""
+    c = DECODE_CHAIN
+    sd = decode_chain_weights()
+    g = torch.Generator().manual_seed(c["seed"] + 2)
+    x = torch.randn(len(rows), c["s0"], c["D"], generator=g) * 0.3
+    for i, r in enumerate(rows):
+        x[i, -1] = sd["llama_model.model.embed_tokens.weight"][DECODE_CHAINS[r][0]]
+    return x
+
+
 def ve_stem_weights(prefix: str, g, sd, dim_in: int = 1):
     c = dim_in
     for idx in (0, 3, 6, 9, 12):

@@ -87,6 +87,7 @@ class _ToyModel:
             t.copy_(torch.randn(t.shape, generator=g))
         self.store.flat_v.abs_()
         self.store.step = 17
+        self.store.set_module_steps({"expert_adaptor": 17, "VETokenizer": 11, "VEInstructor": 9})   # modules step separately
 
     def state_dict(self):
         return {n: to_reference_layout(self.store.p[n], r).clone() for n, _, r in self.store.specs}
@@ -98,6 +99,28 @@ class _ToyModel:
                 self.store.p[n].copy_(from_reference_layout(sd[n].float(), i))
 
 
+def test_optimizer_indices_follow_the_reference_named_parameters_order():
+    """tests/golden/param_order.json = named_parameters() of the reference's own networks.py modules registered in
+    Myriad.__init__'s order, split into RunnerBase.optimizer's two groups (tools/make_golden_host.py --param-order)."""
+    import json
+    from myriad_amd.lora import lora_param_specs
+    from myriad_amd.myriad import uses_weight_decay
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "param_order.json")))
+    ref_names = [n for n, _ in g["named_parameters"]]
+    shapes = {n: tuple(s) for n, s in g["named_parameters"]}
+    specs = ([("expert_adaptor.conv1.weight", (4, 1408), (4, 1408)), ("expert_adaptor.conv2.weight", (1408, 4), (1408, 4))]
+             + ve_param_specs("VETokenizer.", 4096, 5) + [("VETokenizer.base_prompts", (9, 4096), (9, 4096))]
+             + ve_param_specs("VEInstructor.", 768, 1))
+    assert {n: tuple(r) for n, _, r in specs} == shapes                       # same tensors, same reference shapes
+    assert C.reference_param_order([n for n, _, _ in specs][::-1]) == ref_names
+    store = ParamStore(lora_param_specs(2, 64, 8) + specs, "cpu")             # LoRA first in the flat buffer: irrelevant here
+    order, n_wd = C._optimizer_index(store)
+    lora = [n for n in order if "lora_" in n]
+    assert order[:n_wd] == g["weight_decay_group"] + lora and order[n_wd:] == g["no_decay_group"]
+    assert [n.split("self_attn.")[1].rsplit(".default", 1)[0] for n in lora[:4]] == g["peft_lora_order_restated"]
+    assert all(uses_weight_decay(n, len(shapes.get(n, (1, 1)))) for n in order[:n_wd])
+
+
 def test_checkpoint_round_trip_and_torch_adamw_compat(tmp_path):
     m = _ToyModel()
     mgr = C.CheckpointManager(str(tmp_path), max_checkpoints=2)
@@ -105,25 +128,42 @@ def test_checkpoint_round_trip_and_torch_adamw_compat(tmp_path):
     assert [os.path.exists(p) for p in paths] == [False, True, True]               # history cap (runner_base.py:618-626)
     ck = torch.load(paths[-1], map_location="cpu")
     assert set(ck) == {"model", "optimizer", "config", "scaler", "epoch"} and ck["scaler"] is None and ck["epoch"] == 2
-    assert list(ck["model"]) == [n for n, _, _ in m.store.specs]
-    # the optimizer block is a valid torch.optim.AdamW state for the reference's two parameter groups
-    ref_params = [torch.nn.Parameter(v.clone()) for v in ck["model"].values()]
-    n_wd = len(ck["optimizer"]["param_groups"][0]["params"])
-    opt = torch.optim.AdamW([{"params": ref_params[:n_wd], "weight_decay": 0.05}, {"params": ref_params[n_wd:], "weight_decay": 0.0}],
-                            lr=1e-4, betas=(0.9, 0.999))
+    assert sorted(ck["model"]) == sorted(n for n, _, _ in m.store.specs)
+    # the optimizer block is a valid torch.optim.AdamW state for the reference's two parameter groups, built the
+    # reference's way: parameters in named_parameters() order, weight-decay group first (runner_base.py:110-131)
+    order = C.reference_param_order(list(ck["model"]))
+    shapes = {n: r for n, _, r in m.store.specs}
+    wd = [n for n in order if not (len(shapes[n]) < 2 or "bias" in n or "ln" in n or "bn" in n)]
+    nwd = [n for n in order if n not in wd]
+    ref_params = {n: torch.nn.Parameter(ck["model"][n].clone()) for n in order}
+    opt = torch.optim.AdamW([{"params": [ref_params[n] for n in wd], "weight_decay": 0.05},
+                             {"params": [ref_params[n] for n in nwd], "weight_decay": 0.0}], lr=1e-4, betas=(0.9, 0.999))
     opt.load_state_dict(ck["optimizer"])
-    for i, ((name, ishape, rshape), p) in enumerate(zip(m.store.specs, ref_params)):
-        st = opt.state[p]
+    ishapes = {n: i for n, i, _ in m.store.specs}
+    steps = {"expert_adaptor": 17.0, "VETokenizer": 11.0, "VEInstructor": 9.0}
+    for name in order:
+        st = opt.state[ref_params[name]]
         o, n = m.store.offsets[name]
-        assert float(st["step"]) == 17.0 and st["exp_avg"].shape == tuple(rshape)
-        assert torch.equal(st["exp_avg"], to_reference_layout(m.store.flat_m[o:o + n].view(ishape), rshape))
-        assert (name.endswith("bias") or len(rshape) < 2) == (i >= n_wd)
+        assert float(st["step"]) == steps[name.split(".")[0]] and st["exp_avg"].shape == tuple(shapes[name])
+        assert torch.equal(st["exp_avg"], to_reference_layout(m.store.flat_m[o:o + n].view(ishapes[name]), shapes[name]))
+        assert torch.equal(st["exp_avg_sq"], to_reference_layout(m.store.flat_v[o:o + n].view(ishapes[name]), shapes[name]))
     # ... and a state written by torch loads back into the flat buffers
     m2 = _ToyModel()
     m2.store.flat_p.zero_(); m2.store.flat_m.zero_(); m2.store.flat_v.zero_(); m2.store.step = 0
+    m2.store.set_module_steps({})
     assert C.CheckpointManager.load(m2, paths[-1]) == 3                            # resume at epoch + 1
     for a, b in ((m.store.flat_p, m2.store.flat_p), (m.store.flat_m, m2.store.flat_m), (m.store.flat_v, m2.store.flat_v)):
         assert torch.equal(a, b)
-    assert m2.store.step == 17
+    assert m2.store.module_steps() == m.store.module_steps() and m2.store.step == 17
     with pytest.raises(RuntimeError):
         C.CheckpointManager.load(m2, str(tmp_path / "nope.pth"))
+
+
+def test_a_module_that_never_stepped_has_no_optimizer_state(tmp_path):
+    """torch creates AdamW state lazily: a module skipped by every step so far (grad None in the reference) has no entry."""
+    m = _ToyModel()
+    m.store.set_module_steps({"expert_adaptor": 3, "VETokenizer": 0, "VEInstructor": 2})
+    sd = C.optimizer_state_dict(m.store, lr=1e-4)
+    order, _ = C._optimizer_index(m.store)
+    have = {order[i] for i in sd["state"]}
+    assert have == {n for n in order if not n.startswith("VETokenizer.")}

@@ -41,8 +41,13 @@ def test_vision_expert_vs_reference_golden(name):
     assert zmap.shape == (cfg["B"], 1, 224, 224) and omask.shape == (cfg["B"], 1, 16, 16)
     # one trunk pass over [images ; references] must give the same four tensors (batch rows are independent)
     (zmap2, zmask2), (omap2, omask2) = ex.forward(images, text, refs)
-    for a, b in ((zmap, zmap2), (zmask, zmask2), (omap, omap2), (omask, omask2)):
-        assert (a - b).abs().max() < 2e-3
+    # ... up to the GEMM policy: with a split-K scratch registered the K split count depends on M, the fp32 partial sums are
+    # added in a different order, and 100 * cosine logits amplify a flipped bf16 rounding just as they do against the golden
+    # above (same tolerances; bit-equal when no scratch is registered, i.e. when this file runs alone)
+    for a, b in ((zmap, zmap2), (zmask, zmask2)):
+        assert (a - b).abs().max() < 8e-2 and (a - b).abs().mean() < 5e-3
+    for a, b in ((omap, omap2), (omask, omask2)):
+        assert (a - b).abs().max() < 1e-2
 
 
 def test_map_head_kernels_vs_torch():

@@ -112,11 +112,11 @@ def test_vit_prefetch_on_a_side_stream_changes_nothing(model):
     while this step runs: three optimisation steps over three different batches must leave bit-identical losses, parameters
     and AdamW moments compared with the inline order."""
     st = model.store
-    keep = (st.flat_p.clone(), st.flat_m.clone(), st.flat_v.clone(), st.step)
+    keep = (st.flat_p.clone(), st.flat_m.clone(), st.flat_v.clone(), st.step, st.steps_dev.clone())
     batches = [samples(2, seed=31 + i) for i in range(3)]
 
     def run(lookahead):
-        st.flat_p.copy_(keep[0]); st.flat_m.copy_(keep[1]); st.flat_v.copy_(keep[2]); st.step = keep[3]
+        st.flat_p.copy_(keep[0]); st.flat_m.copy_(keep[1]); st.flat_v.copy_(keep[2]); st.step = keep[3]; st.steps_dev.copy_(keep[4])
         losses = []
         for i, b in enumerate(batches):
             nxt = batches[i + 1] if (lookahead and i + 1 < len(batches)) else None
@@ -132,5 +132,5 @@ def test_vit_prefetch_on_a_side_stream_changes_nothing(model):
         assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
         assert not torch.equal(a[1], keep[0])                    # and the steps did move the parameters
     finally:
-        st.flat_p.copy_(keep[0]); st.flat_m.copy_(keep[1]); st.flat_v.copy_(keep[2]); st.step = keep[3]
+        st.flat_p.copy_(keep[0]); st.flat_m.copy_(keep[1]); st.flat_v.copy_(keep[2]); st.step = keep[3]; st.steps_dev.copy_(keep[4])
         model._vit_prefetched = None

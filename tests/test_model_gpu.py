@@ -93,6 +93,44 @@ def test_qformer_fullwidth_fwd_bwd_vs_golden():
 
 
 # ------------------------------------------------------------------------------------------------ LLaMA
+@pytest.mark.parametrize("sampled", [False, True])
+def test_decode_chain_every_generated_id_equals_the_reference(sampled):
+    """KV-cache decode (prefill, eager step, hipGraph replay, packed weight copies) on the peaked-logit fixture generated
+    by the reference's own LLaMA (tests/golden/decode_chain.npz): >= 30 tokens, the eval script's stop ids ([835] and the
+    two-token [2277, 29937] on row 0), the min_length EOS ban, a row that finishes early and is padded.  EVERY id must be
+    equal, at batch 4 and batch 1; with the eval script's `do_sample=True, top_p=0.01, temperature=1.0`
+    (evaluation_aqa_dataset.py:289-301) the kernel-reported p_max proves each step was the arg-max."""
+    g = load("decode_chain")
+    c = gu.DECODE_CHAIN
+    sd = gu.decode_chain_weights()
+    lm = LlamaHIP(sd, c["heads"], DEV, need_backward=False)
+    kw = dict(do_sample=True, top_p=0.01, temperature=1.0) if sampled else {}
+    for name, rows in (("b4", ["row0", "row1", "row2", "row3"]), ("b1", ["row0"]), ("stop835", ["stop835"])):
+        ids = lm.greedy_generate(gu.decode_chain_inputs(rows).to(DEV), max_new_tokens=90, min_length=1, **kw)
+        assert torch.equal(ids, g[name + "_ids"]), (name, ids, g[name + "_ids"])
+        st = lm.last_generate_stats
+        assert st["steps"] == ids.shape[1] and st["sampled_rows"] == 0
+        if sampled:
+            assert st["min_pmax"] >= 0.01
+
+
+def test_top_p_sampling_falls_back_to_a_real_draw_on_flat_logits():
+    """p_max < top_p: HF's warper keeps several tokens and the reference draws among them -- the decode loop must not
+    silently take the arg-max.  Tiny random-weight model: logits are flat (p_max ~ 1/V)."""
+    gd = load("llama_tiny")
+    D, layers, heads, inter, V, seed = [int(x) for x in gd["meta"]]
+    lm = LlamaHIP(gu.llama_weights(D, layers, inter, V, seed=seed, std=0.02), heads, DEV, need_backward=False)
+    emb = gd["emb"][:2, :7].to(DEV)
+    gen = torch.Generator().manual_seed(5)
+    a = lm.greedy_generate(emb, max_new_tokens=6, stop_ids=(), do_sample=True, top_p=0.9, generator=gen)
+    st = dict(lm.last_generate_stats)
+    assert st["sampled_rows"] > 0 and st["min_pmax"] < 0.9
+    b = lm.greedy_generate(emb, max_new_tokens=6, stop_ids=(), do_sample=True, top_p=0.9, generator=torch.Generator().manual_seed(5))
+    assert torch.equal(a, b)                                                    # reproducible through the generator
+    greedy = lm.greedy_generate(emb, max_new_tokens=6, stop_ids=())
+    assert lm.last_generate_stats["sampled_rows"] == 0 and greedy.shape == a.shape
+
+
 def test_llama_fullwidth_loss_and_input_grad_vs_golden():
     g = load("llama_fullwidth")
     D, layers, heads, inter, V, seed = [int(x) for x in g["meta"]]
@@ -285,7 +323,7 @@ def test_myriad_generate_token_ids_vs_oracle(composite):
     model = MyriadHIP(sd, dict(need_backward=False), device=DEV)
     model.eval()
     smp = dict(image=image, anomaly_maps=maps, before_ids=before, after_ids=after)
-    out = model.generate(smp, max_new_tokens=10, stop_ids=((5,),))
+    out = model.generate(smp, max_new_tokens=10, stop_ids=((5,),), min_length=1)
     ids = out["token_ids"]
     assert out["ve_anomaly_maps"].shape == maps.shape
     with torch.no_grad():

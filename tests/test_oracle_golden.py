@@ -113,6 +113,21 @@ def test_llama_tiny_loss_logits_grad_and_greedy():
     close(margins, g["gen_margins"], rtol=1e-3, atol=1e-4)
 
 
+def test_decode_chain_every_id_equals_the_reference():
+    """Peaked-logit fixture (tools/make_golden.py case_decode_chain: the reference's forward(use_cache=True) loop with HF's
+    sample-loop bookkeeping): the eval script's stop ids, the min_length EOS ban, an early-finished row, 835 on a row that
+    is not row 0.  No margin gating: every id equal."""
+    g = load("decode_chain")
+    c = gu.DECODE_CHAIN
+    sd = gu.decode_chain_weights()
+    for name, rows in (("b4", ["row0", "row1", "row2", "row3"]), ("b1", ["row0"]), ("stop835", ["stop835"])):
+        with torch.no_grad():
+            ids = R.greedy_generate(sd, gu.decode_chain_inputs(rows), c["heads"], max_new_tokens=90, min_length=1)
+        assert torch.equal(ids, g[name + "_ids"]), (name, ids, g[name + "_ids"])
+    assert g["b4_ids"].shape[1] == 32 and g["b4_ids"][0, -2:].tolist() == [2277, 29937]      # two-token stop on row 0
+    assert g["b4_ids"][2, 3:].eq(2).all() and g["b4_ids"][3, 1] == 835                          # padded row; 835 off row 0
+
+
 def test_llama_fullwidth_layer():
     g = load("llama_fullwidth")
     D, layers, heads, inter, V, seed = [int(x) for x in g["meta"]]

@@ -226,30 +226,70 @@ def case_qformer(M):
          denc_sub=enc.grad[:, ::4, ::8], meta=np.array([D, layers, heads, inter, enc_w, 302]))
 
 
-def _ref_greedy(lm, inputs_embeds, max_new, stop_ids=((835,), (2277, 29937)), eos=2):
-    """15-line manual loop over the reference's own forward(use_cache=True, past_key_values=tuple,
-    position_ids) -- HF generate() is unavailable for this class under transformers>=4.50."""
+def _ref_greedy(lm, inputs_embeds, max_new, stop_ids=((835,), (2277, 29937)), eos=2, min_length=1):
+    """Manual loop over the reference's own forward(use_cache=True, past_key_values=tuple, position_ids) -- HF
+    generate() is unavailable for this class under transformers>=4.50.  The bookkeeping around the forward
+    is GenerationMixin.sample's (transformers 4.28): EOS banned while fewer than min_length tokens exist, finished rows
+    emit pad (= eos, myriad.py:183), the loop ends when every row is finished or the criterion fires on row 0."""
     B, S0, _ = inputs_embeds.shape
     past, ids, margins = None, [], []
     x, total = dict(inputs_embeds=inputs_embeds), S0
+    unfinished = torch.ones(B, dtype=torch.long)
     for step in range(max_new):
         pos = None if past is None else torch.full((B, 1), total - 1, dtype=torch.long)
         out = lm(**x, attention_mask=torch.ones(B, total, dtype=torch.long), position_ids=pos, past_key_values=past,
                  use_cache=True, return_dict=True)
         past = out.past_key_values
         logits = out.logits[:, -1].clone()
-        if step < 1:
+        if step < min_length:
             logits[:, eos] = -float("inf")
         t2 = logits.topk(2, -1).values
         margins.append(t2[:, 0] - t2[:, 1])
+        _ref_greedy.pmax.append(logits.softmax(-1).max(-1).values)
         nxt = logits.argmax(-1)
+        nxt = nxt * unfinished + eos * (1 - unfinished)
+        unfinished = unfinished * (nxt != eos).long()
         ids.append(nxt)
         row0 = [int(t[0]) for t in ids]
         if any(len(row0) >= len(s) and row0[-len(s):] == list(s) for s in stop_ids):
             break
+        if int(unfinished.max()) == 0:
+            break
         x = dict(input_ids=nxt[:, None])
         total += 1
     return torch.stack(ids, 1), torch.stack(margins, 1)
+
+
+_ref_greedy.pmax = []
+
+
+def case_decode_chain(M):
+    """Peaked-logit decode fixture: >= 30 tokens with every top-1/top-2 margin >= 0.5, the eval script's stop ids."""
+    c = gu.DECODE_CHAIN
+    sd = gu.decode_chain_weights()
+    lm = ref_llama(M, c["D"], c["layers"], c["heads"], c["inter"], c["vocab"])
+    load_sd(lm, sd, "llama_model.")
+    out = {}
+    with torch.no_grad():
+        for name, rows in (("b4", ["row0", "row1", "row2", "row3"]), ("b1", ["row0"]), ("stop835", ["stop835"])):
+            _ref_greedy.pmax = []
+            ids, margins = _ref_greedy(lm, gu.decode_chain_inputs(rows), 90)
+            pmax = torch.stack(_ref_greedy.pmax, 1)
+            live = torch.cat([torch.ones(ids.shape[0], 1, dtype=torch.bool), (ids[:, :-1] == 2).cumsum(1) == 0], 1)
+            assert float(margins[live].min()) >= 0.5, (name, margins[live].min())    # finished rows are padded, not decoded
+            # the eval script samples with top_p = 0.01 (evaluation_aqa_dataset.py:289-301): with p_max >= 0.01 at every live step
+            # HF's warper keeps exactly the arg-max, so these ids are also what that call returns
+            assert float(pmax[live].min()) >= 0.5, (name, pmax[live].min())
+            out[name + "_pmax"] = pmax
+            for i, r in enumerate(rows):          # the engineered chain is what the reference generates
+                want = gu.DECODE_CHAINS[r][1:]
+                got = ids[i].tolist()[:len(want)]
+                n = min(len(want), len(got))
+                assert got[:n] == want[:n], (name, r, got, want)
+            out[name + "_ids"], out[name + "_margins"] = ids, margins
+    assert out["b4_ids"].shape[1] == 32 and out["b4_ids"][0, -2:].tolist() == [2277, 29937]
+    assert out["stop835_ids"].shape[1] == 3
+    save("decode_chain", **out)
 
 
 def case_llama(M):
@@ -434,7 +474,8 @@ def case_optim(M):
          gp=torch.stack([x[0] for x in grads]), gb=torch.stack([x[1] for x in grads]), p3=p.detach(), b3=b.detach())
 
 
-CASES = dict(vit=case_vit, networks=case_networks, qformer=case_qformer, llama=case_llama, clamp_ce=case_clamp_ce,
+CASES = dict(vit=case_vit, networks=case_networks, qformer=case_qformer, llama=case_llama, decode_chain=case_decode_chain,
+             clamp_ce=case_clamp_ce,
              composite=case_composite, optim=case_optim)
 
 if __name__ == "__main__":

@@ -132,5 +132,37 @@ def main():
     print("wrote eval_rules.json, eval_protocol.json, ckpt_io.npz")
 
 
+def param_order_golden(ref):
+    """tests/golden/param_order.json: `named_parameters()` order, shapes and RunnerBase.optimizer's two-group split
+    (runner_base.py:110-119) of Myriad's trainable modules, built from the REFERENCE's own networks.py classes registered
+    in Myriad.__init__'s order (myriad.py:117-125).  The LoRA block follows peft's module tree (q_proj before v_proj,
+    lora_A before lora_B; peft itself is not installed here, so that part is a restated order, marked as such)."""
+    spec = importlib.util.spec_from_file_location("ref_networks", os.path.join(ref, "minigpt4/models/networks.py"))
+    N = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(N)
+
+    class Tree(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.expert_adaptor = N.LoraAdaptorV2(dims=1408, input_dim=4)
+            self.VETokenizer = N.VETokenizer()
+            self.VEInstructor = N.VEInstructorV2()
+
+    t = Tree()
+    names = [(n, list(p.shape)) for n, p in t.named_parameters() if p.requires_grad]
+    wd, nwd = [], []
+    for n, shp in names:
+        (nwd if (len(shp) < 2 or "bias" in n or "ln" in n or "bn" in n) else wd).append(n)
+    out = {"named_parameters": names, "weight_decay_group": wd, "no_decay_group": nwd,
+           "peft_lora_order_restated": ["q_proj.lora_A", "q_proj.lora_B", "v_proj.lora_A", "v_proj.lora_B"]}
+    path = os.path.join(ROOT, "tests", "golden", "param_order.json")
+    json.dump(out, open(path, "w"), indent=1)
+    print("wrote", path, len(names), "parameters")
+
+
 if __name__ == "__main__":
-    main()
+    if "--param-order" in sys.argv:
+        param_order_golden("/root/reference")
+    else:
+        main()
+        param_order_golden("/root/reference")

@@ -16,7 +16,7 @@ model = MyriadHIP(SyntheticWeights(cfg, dev, seed=0), dict(fixed_stage=1, fixed_
                                                              qf_heads=cfg["qf_heads"], llm_heads=cfg["llm_heads"], use_lora=True),
                   device=dev)
 st = model.store
-keep = (st.flat_p.clone(), st.flat_m.clone(), st.flat_v.clone(), st.step, model.lora.step_seed)
+keep = (st.flat_p.clone(), st.flat_m.clone(), st.flat_v.clone(), st.step, model.lora.step_seed, st.steps_dev.clone())
 batches = [make_samples(b, cfg["vocab"], 100 + i, dev) for i, b in enumerate((8, 8, 4, 8, 2, 8, 8))]
 
 
@@ -25,7 +25,7 @@ def digest(t):
 
 
 def run(side: bool):
-    st.flat_p.copy_(keep[0]); st.flat_m.copy_(keep[1]); st.flat_v.copy_(keep[2]); st.step = keep[3]
+    st.flat_p.copy_(keep[0]); st.flat_m.copy_(keep[1]); st.flat_v.copy_(keep[2]); st.step = keep[3]; st.steps_dev.copy_(keep[5])
     model.lora.step_seed = keep[4]                   # the LoRA dropout masks are a function of (step, layer)
     model._leaf_aside = side
     model.llama.defer_lora_wgrad = side

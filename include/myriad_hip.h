@@ -122,6 +122,17 @@ int mh_rope_inplace(void* x, int ld, int col0, int n_tok, int n_heads, int head_
 /* K9 SiLU-gated MLP elementwise (modeling_llama.py:139-140): gu = [M, 2I] = [gate | up] bf16. */
 int mh_silu_mul_fwd(const void* gu, void* h, int M, int I, mh_stream_t s);
 int mh_silu_mul_bwd(const void* dh, const void* gu, void* dgu, int M, int I, mh_stream_t s);
+/* the same with gate / up interleaved in blocks of `blk` columns ([g 0..blk-1 | u 0..blk-1 | g blk.. ]; blk = 0: the halves
+   layout above), and the SiLU-gated MLP fused into the GEMMs around it (modeling_llama.py:139-140): gu[M, 2I] = X Wgu^T with
+   Wgu's rows interleaved in blocks of 128, act[M, I] = silu(g) * u from the gate|up GEMM's epilogue; dgu = silu_mul_bwd(dH
+   WdT^T, gu) from the down projection's dgrad epilogue (dact_buf [M, I] bf16: scratch when the policy does not run the fused
+   kernel).  Same bits as GEMM + mh_silu_mul_*_blk. */
+int mh_silu_mul_fwd_blk(const void* gu, void* h, int M, int I, int blk, mh_stream_t s);
+int mh_silu_mul_bwd_blk(const void* dh, const void* gu, void* dgu, int M, int I, int blk, mh_stream_t s);
+int mh_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int ldw, void* gu, int ldgu, void* act, int ldact, int M,
+                       int I, int K, mh_stream_t s);
+int mh_gemm_swiglu_bwd(const void* dH, int lddh, const void* WdT, int ldw, const void* gu, int ldgu, void* dgu, int lddgu,
+                       void* dact_buf, int M, int I, int K, mh_stream_t s);
 /* erf-GELU on bf16 (Qformer.py:352-356 via ACT2FN["gelu"]) */
 int mh_gelu_fwd(const void* x, void* y, long n, mh_stream_t s);
 int mh_gelu_bwd(const void* dy, const void* x, void* dx, long n, mh_stream_t s);
@@ -218,6 +229,17 @@ int mh_scale_f32(float* x, float a, long n, mh_stream_t s);
 /* K15 AdamW (runner_base.py:104-139) on a flat f32 buffer with optional bf16 shadow; step is 1-based. */
 int mh_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf16, long n, double lr, double beta1,
                   double beta2, double eps, double weight_decay, int step, double grad_scale, mh_stream_t s);
+
+/* K18 data path: NSA / CutPaste self-supervised anomaly augmentation on uint8 crops resident in HBM --
+   minigpt4/datasets/self_sup_tasks.py:254-268 (the 'swap' and 'uniform' blends) and :97-113 (the label).  The random patch
+   geometry is sampled on the host exactly as the reference samples it (myriad_amd/self_sup.py); ops is a device array of
+   48-byte records {int image, y0, x0, h, w, sy, sx, mode (0 swap / 1 uniform); long mask_off; double factor}, masks the
+   byte pool the records index, hs / ws HOST copies of h, w.  out starts as a copy of dest; union_mask [B,H,W] u8 zeroed.
+   mh_patch_label: mode 0 binary, 1 continuous (factor [B] f64), 2 intensity, 3 logistic-intensity (k, x0). */
+int mh_patch_blend_u8(void* out, const void* src, const void* masks, const void* ops, const int* hs, const int* ws,
+                      int n_ops, int B, int H, int W, void* union_mask, mh_stream_t s);
+int mh_patch_label(const void* dest, const void* out, const void* union_mask, void* sums_ws, void* lm_ws, float* label,
+                   const double* factor, int B, int H, int W, int mode, int tol, double k, double x0, mh_stream_t s);
 
 /* Gated AdamW: torch.optim.AdamW skips parameters whose .grad is None -- a module no rank used this step (random prompt
    stage, myriad.py:378; DDP find_unused_parameters, runner_base.py:96-98) keeps its parameters, moments and step count.

@@ -182,79 +182,86 @@ __global__ __launch_bounds__(AS_NW * 64) void attn_seq_fwd_kernel(AttnSeqParams 
     as_stage_issue(st, kb, vb, p.ld, S, rows, pos);
     as_stage_commit(st, Ks, Vs, S, rows, p.cos_tab, p.sin_tab);
   }
-  // this wave's query rows (rotated), loaded while the images settle
-  short8_t qfs[2][4];
-#pragma unroll
-  for (int which = 0; which < 2; ++which) {
-    const int f = as_own(nf, wave, which);
-    if (f >= 0) as_row_frags<true>(qfs[which], qb, p.ld, 16 * f + lr, S, lg, pos, p.cos_tab, p.sin_tab);
+  // this wave's query rows (rotated), loaded while the images settle.  The loops below are ROLLED on purpose: the first
+  // version unrolled fragments x key chunks into 37 KB (forward) / 90 KB (backward) of straight-line code that every
+  // workgroup executes exactly once -- instruction-fetch bound (55-60 us per workgroup even on an idle chip).
+  short8_t qa[4], qn[4];
+  {
+    const int f0 = as_own(nf, wave, 0), f1 = as_own(nf, wave, 1);
+    if (f0 >= 0) as_row_frags<true>(qa, qb, p.ld, 16 * f0 + lr, S, lg, pos, p.cos_tab, p.sin_tab);
+    if (f1 >= 0) as_row_frags<true>(qn, qb, p.ld, 16 * f1 + lr, S, lg, pos, p.cos_tab, p.sin_tab);
   }
   __syncthreads();
 
-#pragma unroll
+#pragma unroll 1
   for (int which = 0; which < 2; ++which) {
     const int f = as_own(nf, wave, which);
-    if (f < 0) continue;
-    const int qi = 16 * f + lr;
-    short8_t (&qf)[4] = qfs[which];
-    float4_t s[AS_MAXF];
-    float tmax = AS_NEG_INF;
+    if (f >= 0) {
+      const int qi = 16 * f + lr;
+      float4_t acc[8];
 #pragma unroll
-    for (int j = 0; j < AS_MAXF; ++j) {
-      s[j] = (float4_t){0.f, 0.f, 0.f, 0.f};
-      if (j <= f) {                                   // wave-uniform: causal, Sq == Sk
+      for (int jd = 0; jd < 8; ++jd) acc[jd] = (float4_t){0.f, 0.f, 0.f, 0.f};
+      float mrun = AS_NEG_INF, lsum = 0.f;          // per-lane partial row sum (its 8 keys per chunk); combined at the end
+#pragma unroll 1
+      for (int c = 0; 2 * c <= f; ++c) {            // 32 keys per step; causal: key fragments 0 .. f
+        float4_t s[2];
+        float tmax = AS_NEG_INF;
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-          s[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag_rm(Ks, j, kk, lr, lg), qf[kk], s[j], 0, 0, 0);
+        for (int u = 0; u < 2; ++u) {
+          const int j = 2 * c + u;
+          s[u] = (float4_t){0.f, 0.f, 0.f, 0.f};
+          if (j <= f) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = 16 * j + 4 * lg + r;
-          const bool ok = key < kv_valid && key <= qi && qi < S;
-          s[j][r] = ok ? s[j][r] * p.scale : AS_NEG_INF;
-          tmax = fmaxf(tmax, s[j][r]);
+            for (int kk = 0; kk < 4; ++kk)
+              s[u] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag_rm(Ks, j, kk, lr, lg), qa[kk], s[u], 0, 0, 0);
+          }
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int key = 16 * j + 4 * lg + r;
+            const bool ok = j <= f && key < kv_valid && key <= qi && qi < S;
+            s[u][r] = ok ? s[u][r] * p.scale : AS_NEG_INF;
+            tmax = fmaxf(tmax, s[u][r]);
+          }
         }
-      } else {
-        s[j] = (float4_t){AS_NEG_INF, AS_NEG_INF, AS_NEG_INF, AS_NEG_INF};
-      }
-    }
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
-    tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
-    float lsum = 0.f;
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 16, 64));
+        tmax = fmaxf(tmax, __shfl_xor(tmax, 32, 64));
+        const float m_new = fmaxf(mrun, tmax);
+        const float alpha = (m_new == AS_NEG_INF) ? 1.f : __expf(mrun - m_new);
+        float psum = 0.f;
 #pragma unroll
-    for (int j = 0; j < AS_MAXF; ++j)
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const float e = (tmax == AS_NEG_INF) ? 0.f : __expf(s[j][r] - tmax);
-        s[j][r] = e;
-        lsum += e;
-      }
-    lsum += __shfl_xor(lsum, 16, 64);
-    lsum += __shfl_xor(lsum, 32, 64);
-
-    float4_t acc[8];
+          for (int r = 0; r < 4; ++r) {
+            const float e = (m_new == AS_NEG_INF) ? 0.f : __expf(s[u][r] - m_new);
+            s[u][r] = e;
+            psum += e;
+          }
+        lsum = lsum * alpha + psum;
+        mrun = m_new;
+        const short8_t pb = as_pack8(s[0], s[1]);
 #pragma unroll
-    for (int jd = 0; jd < 8; ++jd) acc[jd] = (float4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < AS_MAXF / 2; ++c) {
-      if (2 * c <= f) {
-        const short8_t pb = as_pack8(s[2 * c], s[2 * c + 1]);
-#pragma unroll
-        for (int jd = 0; jd < 8; ++jd)
+        for (int jd = 0; jd < 8; ++jd) {
+          acc[jd] *= alpha;
           acc[jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag_tr(Vs, jd, c, lr, lg), pb, acc[jd], 0, 0, 0);
+        }
       }
-    }
-    if (qi < S) {
-      const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
-      bf16_t* ob = p.o + ((long)b * S + qi) * p.ldo + h * AS_D;
+      lsum += __shfl_xor(lsum, 16, 64);
+      lsum += __shfl_xor(lsum, 32, 64);
+      if (qi < S) {
+        const float inv = lsum > 0.f ? 1.f / lsum : 0.f;
+        bf16_t* ob = p.o + ((long)b * S + qi) * p.ldo + h * AS_D;
 #pragma unroll
-      for (int jd = 0; jd < 8; ++jd) {
-        uint2 pk;
-        pk.x = pack_bf2(acc[jd][0] * inv, acc[jd][1] * inv);
-        pk.y = pack_bf2(acc[jd][2] * inv, acc[jd][3] * inv);
-        *reinterpret_cast<uint2*>(ob + jd * 16 + lg * 4) = pk;
+        for (int jd = 0; jd < 8; ++jd) {
+          uint2 pk;
+          pk.x = pack_bf2(acc[jd][0] * inv, acc[jd][1] * inv);
+          pk.y = pack_bf2(acc[jd][2] * inv, acc[jd][3] * inv);
+          *reinterpret_cast<uint2*>(ob + jd * 16 + lg * 4) = pk;
+        }
+        if (p.lse && lg == 0) p.lse[((long)b * p.H + h) * S + qi] = (lsum > 0.f) ? mrun + __logf(lsum) : AS_NEG_INF;
       }
-      if (p.lse && lg == 0) p.lse[((long)b * p.H + h) * S + qi] = (lsum > 0.f) ? tmax + __logf(lsum) : AS_NEG_INF;
     }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) qa[kk] = qn[kk];        // second fragment's rows move into the working set
   }
 }
 
@@ -342,16 +349,22 @@ __global__ __launch_bounds__(AS_NW * 64) void attn_seq_bwd_kernel(AttnSeqParams 
   }
   for (int i = threadIdx.x; i < AS_MAXF * 16; i += AS_NW * 64) lse_s[i] = i < S ? p.lse[((long)b * p.H + h) * S + i] : 1e30f;
 
-  // this wave's query rows: Q (rotated), dO (slab sums) and delta, loaded while the images settle
-  short8_t qf[2][4], gf[2][4];
-  float dlts[2] = {0.f, 0.f};
+  // this wave's query rows: Q (rotated), dO (slab sums) and delta, loaded while the images settle.  Two register sets
+  // (first / second owned fragment); the loops over fragments and key chunks are rolled (see the forward kernel) and work
+  // on set 0, the sets are exchanged at the end of each fragment iteration.
+  short8_t qf0[4], gf0[4], qf1[4], gf1[4];
+  float dlt0 = 0.f, dlt1 = 0.f;
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
+    short8_t (&qf)[4] = which ? qf1 : qf0;
+    short8_t (&gf)[4] = which ? gf1 : gf0;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { qf[kk] = (short8_t){0, 0, 0, 0, 0, 0, 0, 0}; gf[kk] = qf[kk]; }
     const int f = as_own(nf, wave, which);
     if (f < 0) continue;
     const int qi = 16 * f + lr;
-    as_row_frags<true>(qf[which], qb, p.ld, qi, S, lg, pos, p.cos_tab, p.sin_tab);
-    as_dout_frags(gf[which], p, (long)b * S + qi, h * AS_D, qi < S, lg);
+    as_row_frags<true>(qf, qb, p.ld, qi, S, lg, pos, p.cos_tab, p.sin_tab);
+    as_dout_frags(gf, p, (long)b * S + qi, h * AS_D, qi < S, lg);
     // delta = sum_d dO * O over this lane's columns, combined across the row's four lanes
     short8_t of[4];
     as_row_frags<false>(of, p.o_in + (long)b * S * p.ldo + h * AS_D, p.ldo, qi, S, lg, pos, nullptr, nullptr);
@@ -359,134 +372,150 @@ __global__ __launch_bounds__(AS_NW * 64) void attn_seq_bwd_kernel(AttnSeqParams 
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) dlt += bf2f((bf16_t)of[kk][e]) * bf2f((bf16_t)gf[which][kk][e]);
+      for (int e = 0; e < 8; ++e) dlt += bf2f((bf16_t)of[kk][e]) * bf2f((bf16_t)gf[kk][e]);
     dlt += __shfl_xor(dlt, 16, 64);
     dlt += __shfl_xor(dlt, 32, 64);
     if (lg == 0) dlt_s[qi] = dlt;
-    dlts[which] = dlt;
+    if (which) dlt1 = dlt; else dlt0 = dlt;
   }
   __syncthreads();
 
   // ---------------- phase A
-#pragma unroll
+#pragma unroll 1
   for (int which = 0; which < 2; ++which) {
     const int f = as_own(nf, wave, which);
-    if (f < 0) continue;
-    const int qi = 16 * f + lr;
-    const float dlt = dlts[which];
-    const float lse = lse_s[qi];
-    float4_t acc[8];
+    if (f >= 0) {
+      const int qi = 16 * f + lr;
+      const float dlt = dlt0, lse = lse_s[qi];
+      float4_t acc[8];
 #pragma unroll
-    for (int jd = 0; jd < 8; ++jd) acc[jd] = (float4_t){0.f, 0.f, 0.f, 0.f};
+      for (int jd = 0; jd < 8; ++jd) acc[jd] = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+      for (int c = 0; 2 * c <= f; ++c) {
+        float4_t ds[2];
 #pragma unroll
-    for (int c = 0; c < AS_MAXF / 2; ++c) {
-      if (2 * c > f) continue;
-      float4_t ds[2];
+        for (int u = 0; u < 2; ++u) {
+          const int j = 2 * c + u;
+          ds[u] = (float4_t){0.f, 0.f, 0.f, 0.f};
+          if (j > f) continue;
+          float4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int j = 2 * c + u;
-        ds[u] = (float4_t){0.f, 0.f, 0.f, 0.f};
-        if (j > f) continue;
-        float4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+          for (int kk = 0; kk < 4; ++kk) {
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag_rm(I0, j, kk, lr, lg), qf0[kk], sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag_rm(I1, j, kk, lr, lg), gf0[kk], dp, 0, 0, 0);
+          }
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag_rm(I0, j, kk, lr, lg), qf[which][kk], s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag_rm(I1, j, kk, lr, lg), gf[which][kk], dp, 0, 0, 0);
+          for (int r = 0; r < 4; ++r) {
+            const int key = 16 * j + 4 * lg + r;
+            const bool ok = key < kv_valid && key <= qi && qi < S;
+            const float pr = ok ? __expf(sc[r] * p.scale - lse) : 0.f;
+            ds[u][r] = ok ? pr * (dp[r] - dlt) * p.scale : 0.f;
+          }
         }
+        const short8_t db = as_pack8(ds[0], ds[1]);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = 16 * j + 4 * lg + r;
-          const bool ok = key < kv_valid && key <= qi && qi < S;
-          const float pr = ok ? __expf(s[r] * p.scale - lse) : 0.f;
-          ds[u][r] = ok ? pr * (dp[r] - dlt) * p.scale : 0.f;
-        }
+        for (int jd = 0; jd < 8; ++jd)
+          acc[jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag_tr(I0, jd, c, lr, lg), db, acc[jd], 0, 0, 0);
       }
-      const short8_t db = as_pack8(ds[0], ds[1]);
-#pragma unroll
-      for (int jd = 0; jd < 8; ++jd)
-        acc[jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag_tr(I0, jd, c, lr, lg), db, acc[jd], 0, 0, 0);
+      if (qi < S) {
+        const int ps = pos[qi];
+        as_unrope_store(acc, dqb + (long)qi * p.ld, true, p.cos_tab + (size_t)ps * 64, p.sin_tab + (size_t)ps * 64, lg);
+      }
     }
-    if (qi < S) {
-      const int ps = pos[qi];
-      as_unrope_store(acc, dqb + (long)qi * p.ld, true, p.cos_tab + (size_t)ps * 64, p.sin_tab + (size_t)ps * 64, lg);
-    }
-  }
-  // ---------------- swap the images: keys' rows -> registers, queries' rows -> LDS
-  short8_t kf[2][4], vf[2][4];
-#pragma unroll
-  for (int which = 0; which < 2; ++which) {
-    const int f = as_own_key(nf, wave, which);
-    if (f < 0) continue;
+    // exchange the register sets: the next iteration (and the image swap below) address them by position
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      kf[which][kk] = as_frag_rm(I0, f, kk, lr, lg);
-      vf[which][kk] = as_frag_rm(I1, f, kk, lr, lg);
+      const short8_t tq = qf0[kk], tg = gf0[kk];
+      qf0[kk] = qf1[kk]; gf0[kk] = gf1[kk];
+      qf1[kk] = tq; gf1[kk] = tg;
+    }
+    const float td = dlt0; dlt0 = dlt1; dlt1 = td;
+  }
+  // ---------------- swap the images: keys' rows -> registers, queries' rows -> LDS
+  short8_t kf0[4], vf0[4], kf1[4], vf1[4];
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    short8_t (&kf)[4] = which ? kf1 : kf0;
+    short8_t (&vf)[4] = which ? vf1 : vf0;
+    const int f = as_own_key(nf, wave, which);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      kf[kk] = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
+      vf[kk] = kf[kk];
+      if (f >= 0) {
+        kf[kk] = as_frag_rm(I0, f, kk, lr, lg);
+        vf[kk] = as_frag_rm(I1, f, kk, lr, lg);
+      }
     }
   }
   __syncthreads();
 #pragma unroll
-  for (int which = 0; which < 2; ++which) {
+  for (int which = 0; which < 2; ++which) {          // after two exchanges the sets are back in fragment order
+    short8_t (&qf)[4] = which ? qf1 : qf0;
+    short8_t (&gf)[4] = which ? gf1 : gf0;
     const int f = as_own(nf, wave, which);
     if (f < 0) continue;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      *reinterpret_cast<short8_t*>(I0 + (16 * f + lr) * AS_RS + kk * 32 + lg * 8) = qf[which][kk];
-      *reinterpret_cast<short8_t*>(I1 + (16 * f + lr) * AS_RS + kk * 32 + lg * 8) = gf[which][kk];
+      *reinterpret_cast<short8_t*>(I0 + (16 * f + lr) * AS_RS + kk * 32 + lg * 8) = qf[kk];
+      *reinterpret_cast<short8_t*>(I1 + (16 * f + lr) * AS_RS + kk * 32 + lg * 8) = gf[kk];
     }
   }
   __syncthreads();
   // ---------------- phase B
-#pragma unroll
+#pragma unroll 1
   for (int which = 0; which < 2; ++which) {
     const int f = as_own_key(nf, wave, which);
-    if (f < 0) continue;
-    const int ki = 16 * f + lr;
-    const bool key_ok = ki < kv_valid;
-    float4_t adk[8], adv[8];
-#pragma unroll
-    for (int jd = 0; jd < 8; ++jd) {
-      adk[jd] = (float4_t){0.f, 0.f, 0.f, 0.f};
-      adv[jd] = (float4_t){0.f, 0.f, 0.f, 0.f};
-    }
-#pragma unroll
-    for (int c = 0; c < AS_MAXF / 2; ++c) {
-      if (2 * c + 1 < f || 2 * c >= nf) continue;                // query fragments 2c, 2c+1; causal: queries >= keys
-      float4_t pr[2], ds[2];
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int j = 2 * c + u;
-        pr[u] = (float4_t){0.f, 0.f, 0.f, 0.f};
-        ds[u] = (float4_t){0.f, 0.f, 0.f, 0.f};
-        if (j < f || j >= nf) continue;
-        float4_t s = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk) {
-          s = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag_rm(I0, j, kk, lr, lg), kf[which][kk], s, 0, 0, 0);
-          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag_rm(I1, j, kk, lr, lg), vf[which][kk], dp, 0, 0, 0);
-        }
-        const float4_t l4 = *reinterpret_cast<const float4_t*>(lse_s + 16 * j + 4 * lg);
-        const float4_t d4 = *reinterpret_cast<const float4_t*>(dlt_s + 16 * j + 4 * lg);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int qq = 16 * j + 4 * lg + r;
-          const bool ok = key_ok && qq < S && ki <= qq;
-          const float e = ok ? __expf(s[r] * p.scale - l4[r]) : 0.f;
-          pr[u][r] = e;
-          ds[u][r] = ok ? e * (dp[r] - d4[r]) * p.scale : 0.f;
-        }
-      }
-      const short8_t pb = as_pack8(pr[0], pr[1]), db = as_pack8(ds[0], ds[1]);
+    if (f >= 0) {
+      const int ki = 16 * f + lr;
+      const bool key_ok = ki < kv_valid;
+      float4_t adk[8], adv[8];
 #pragma unroll
       for (int jd = 0; jd < 8; ++jd) {
-        adv[jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag_tr(I1, jd, c, lr, lg), pb, adv[jd], 0, 0, 0);
-        adk[jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag_tr(I0, jd, c, lr, lg), db, adk[jd], 0, 0, 0);
+        adk[jd] = (float4_t){0.f, 0.f, 0.f, 0.f};
+        adv[jd] = (float4_t){0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll 1
+      for (int c = f >> 1; 2 * c < nf; ++c) {          // query fragments 2c, 2c+1; causal: queries at or after the keys
+        float4_t pr[2], ds[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int j = 2 * c + u;
+          pr[u] = (float4_t){0.f, 0.f, 0.f, 0.f};
+          ds[u] = (float4_t){0.f, 0.f, 0.f, 0.f};
+          if (j < f || j >= nf) continue;
+          float4_t sc = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int kk = 0; kk < 4; ++kk) {
+            sc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag_rm(I0, j, kk, lr, lg), kf0[kk], sc, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag_rm(I1, j, kk, lr, lg), vf0[kk], dp, 0, 0, 0);
+          }
+          const float4_t l4 = *reinterpret_cast<const float4_t*>(lse_s + 16 * j + 4 * lg);
+          const float4_t d4 = *reinterpret_cast<const float4_t*>(dlt_s + 16 * j + 4 * lg);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int qq = 16 * j + 4 * lg + r;
+            const bool ok = key_ok && qq < S && ki <= qq;
+            const float e = ok ? __expf(sc[r] * p.scale - l4[r]) : 0.f;
+            pr[u][r] = e;
+            ds[u][r] = ok ? e * (dp[r] - d4[r]) * p.scale : 0.f;
+          }
+        }
+        const short8_t pb = as_pack8(pr[0], pr[1]), db = as_pack8(ds[0], ds[1]);
+#pragma unroll
+        for (int jd = 0; jd < 8; ++jd) {
+          adv[jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag_tr(I1, jd, c, lr, lg), pb, adv[jd], 0, 0, 0);
+          adk[jd] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_frag_tr(I0, jd, c, lr, lg), db, adk[jd], 0, 0, 0);
+        }
+      }
+      if (ki < S) {
+        const int ps = pos[ki];
+        as_unrope_store(adk, dqb + W + (long)ki * p.ld, true, p.cos_tab + (size_t)ps * 64, p.sin_tab + (size_t)ps * 64, lg);
+        as_unrope_store(adv, dqb + 2 * W + (long)ki * p.ld, false, nullptr, nullptr, lg);
       }
     }
-    if (ki < S) {
-      const int ps = pos[ki];
-      as_unrope_store(adk, dqb + W + (long)ki * p.ld, true, p.cos_tab + (size_t)ps * 64, p.sin_tab + (size_t)ps * 64, lg);
-      as_unrope_store(adv, dqb + 2 * W + (long)ki * p.ld, false, nullptr, nullptr, lg);
-    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) { kf0[kk] = kf1[kk]; vf0[kk] = vf1[kk]; }
   }
 }
 

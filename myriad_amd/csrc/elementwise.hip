@@ -53,14 +53,24 @@ extern "C" int mh_rope_inplace(void* x, int ld, int col0, int n_tok, int n_heads
 
 // ---- K9 SiLU-gated MLP: h = silu(g) * u, gu = [M, 2I] = [gate | up] ---------------------------
 // reference modeling_llama.py:139-140
-__global__ void silu_mul_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ h, long M, int I) {
+// blk = 0: gu row = [g 0..I-1 | u 0..I-1]; blk = 128: gate / up interleaved in blocks of blk columns (the layout the fused
+// gate|up GEMM epilogue needs, gemm.hip mh_gemm_swiglu_*): g column c sits at (c / blk) * 2 blk + c % blk, u at + blk
+__device__ __forceinline__ long silu_gcol(int c, int I, int blk, int* ustep) {
+  if (blk == 0) { *ustep = I; return c; }
+  *ustep = blk;
+  return (long)(c / blk) * 2 * blk + (c % blk);
+}
+
+__global__ void silu_mul_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ h, long M, int I, int blk) {
   const int per_row = I >> 3;
   const long total = M * per_row;
   for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
     const long m = it / per_row;
     const int c = (int)(it - m * per_row) * 8;
-    const short8_t g = *reinterpret_cast<const short8_t*>(gu + m * 2 * I + c);
-    const short8_t u = *reinterpret_cast<const short8_t*>(gu + m * 2 * I + I + c);
+    int us;
+    const long gc = silu_gcol(c, I, blk, &us);
+    const short8_t g = *reinterpret_cast<const short8_t*>(gu + m * 2 * I + gc);
+    const short8_t u = *reinterpret_cast<const short8_t*>(gu + m * 2 * I + gc + us);
     short8_t o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -72,14 +82,16 @@ __global__ void silu_mul_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __res
 }
 
 __global__ void silu_mul_bwd_kernel(const bf16_t* __restrict__ dh, const bf16_t* __restrict__ gu,
-                                    bf16_t* __restrict__ dgu, long M, int I) {
+                                    bf16_t* __restrict__ dgu, long M, int I, int blk) {
   const int per_row = I >> 3;
   const long total = M * per_row;
   for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
     const long m = it / per_row;
     const int c = (int)(it - m * per_row) * 8;
-    const short8_t g = *reinterpret_cast<const short8_t*>(gu + m * 2 * I + c);
-    const short8_t u = *reinterpret_cast<const short8_t*>(gu + m * 2 * I + I + c);
+    int us;
+    const long gc = silu_gcol(c, I, blk, &us);
+    const short8_t g = *reinterpret_cast<const short8_t*>(gu + m * 2 * I + gc);
+    const short8_t u = *reinterpret_cast<const short8_t*>(gu + m * 2 * I + gc + us);
     const short8_t d = *reinterpret_cast<const short8_t*>(dh + m * I + c);
     short8_t og, ou;
 #pragma unroll
@@ -90,26 +102,32 @@ __global__ void silu_mul_bwd_kernel(const bf16_t* __restrict__ dh, const bf16_t*
       og[e] = (short)f2bf(dv * uv * (sg + silu * (1.f - sg)));
       ou[e] = (short)f2bf(dv * silu);
     }
-    *reinterpret_cast<short8_t*>(dgu + m * 2 * I + c) = og;
-    *reinterpret_cast<short8_t*>(dgu + m * 2 * I + I + c) = ou;
+    *reinterpret_cast<short8_t*>(dgu + m * 2 * I + gc) = og;
+    *reinterpret_cast<short8_t*>(dgu + m * 2 * I + gc + us) = ou;
   }
 }
 
-extern "C" int mh_silu_mul_fwd(const void* gu, void* h, int M, int I, hipStream_t stream) {
+extern "C" int mh_silu_mul_fwd_blk(const void* gu, void* h, int M, int I, int blk, hipStream_t stream) {
   if (M <= 0) return MH_OK;
-  if (I % 8) return MH_ERR_ARG;
+  if (I % 8 || blk < 0 || (blk && ((blk % 8) || (I % blk)))) return MH_ERR_ARG;
   hipLaunchKernelGGL(silu_mul_fwd_kernel, dim3(ew_grid((long)M * (I / 8))), dim3(EW_NT), 0, stream,
-                     (const bf16_t*)gu, (bf16_t*)h, (long)M, I);
+                     (const bf16_t*)gu, (bf16_t*)h, (long)M, I, blk);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
-extern "C" int mh_silu_mul_bwd(const void* dh, const void* gu, void* dgu, int M, int I, hipStream_t stream) {
+extern "C" int mh_silu_mul_bwd_blk(const void* dh, const void* gu, void* dgu, int M, int I, int blk, hipStream_t stream) {
   if (M <= 0) return MH_OK;
-  if (I % 8) return MH_ERR_ARG;
+  if (I % 8 || blk < 0 || (blk && ((blk % 8) || (I % blk)))) return MH_ERR_ARG;
   hipLaunchKernelGGL(silu_mul_bwd_kernel, dim3(ew_grid((long)M * (I / 8))), dim3(EW_NT), 0, stream,
-                     (const bf16_t*)dh, (const bf16_t*)gu, (bf16_t*)dgu, (long)M, I);
+                     (const bf16_t*)dh, (const bf16_t*)gu, (bf16_t*)dgu, (long)M, I, blk);
   MH_CHECK_LAUNCH();
   return MH_OK;
+}
+extern "C" int mh_silu_mul_fwd(const void* gu, void* h, int M, int I, hipStream_t stream) {
+  return mh_silu_mul_fwd_blk(gu, h, M, I, 0, stream);
+}
+extern "C" int mh_silu_mul_bwd(const void* dh, const void* gu, void* dgu, int M, int I, hipStream_t stream) {
+  return mh_silu_mul_bwd_blk(dh, gu, dgu, M, I, 0, stream);
 }
 
 // ---- GELU (erf form) on bf16, fwd and bwd ----------------------------------------------------

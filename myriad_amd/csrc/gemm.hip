@@ -273,19 +273,9 @@ static int launch_gemm(const GemmArgs& g, hipStream_t stream) {
   return MH_OK;
 }
 
-int mh_launch_gemm_pp(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
-                      const float* bias, const float* residual, int ldr, int flags, float alpha, int splits, int tps,
-                      long split_stride, hipStream_t stream);
-
 int mh_launch_gemm_256(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                        const float* bias, const float* residual, int ldr, int flags, float alpha, int splits, int tps,
-                       long split_stride, hipStream_t stream);
-
-int mh_launch_gemm_stream(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
-                          const float* bias, const float* residual, int ldr, int flags, float alpha, int splits,
-                          int steps_per_split, long split_stride, int nfb, hipStream_t stream);
-void mh_gemm_stream_plan(int M, int N, int K, int can_split, int* nfb, int* splits);
-static int stream_nfb(int M, int N, int K);
+                       long split_stride, hipStream_t stream, void* aux = nullptr, int ldaux = 0);
 
 static int dispatch(const GemmArgs& g, hipStream_t stream) {
   int variant = (g.flags >> MH_GEMM_VARIANT_SHIFT) & 15;
@@ -302,15 +292,9 @@ static int dispatch(const GemmArgs& g, hipStream_t stream) {
     case 8: return launch_gemm<0, 4, 128, 2, 32>(g, stream);   // BK=32: 64 KiB, 2 blocks/CU, 3 tiles in flight
     case 9: return launch_gemm<0, 2, 128, 2, 64, 8>(g, stream);   // 8 waves/block (wave tile 32x64), 2 blocks/CU
     case 10: return launch_gemm<0, 4, 128, 1, 64, 8>(g, stream);  // 8 waves/block, 4-deep ring, 1 block/CU
-    case 11:                                                      // 256x128 ping-pong (gemm_pp.hip), 1 block/CU
-      return mh_launch_gemm_pp(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, g.bias, g.residual, g.ldr, g.flags,
-                               g.alpha, g.splits, g.tps, g.split_stride, stream);
     case 12:                                                      // 256x256x32, 4-deep ring (gemm_256.hip), 1 block/CU
       return mh_launch_gemm_256(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, g.bias, g.residual, g.ldr, g.flags,
                                 g.alpha, g.splits, g.tps, g.split_stride, stream);
-    case 13:                                                      // mid-M weight streaming (gemm_stream.hip)
-      return mh_launch_gemm_stream(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, g.bias, g.residual, g.ldr, g.flags,
-                                   g.alpha, g.splits, g.tps, g.split_stride, stream_nfb(g.M, g.N, g.K), stream);
     default: return MH_ERR_ARG;
   }
 }
@@ -441,12 +425,6 @@ static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t str
   if (((g0.flags >> MH_GEMM_VARIANT_SHIFT) & 15) == 12)
     rc = mh_launch_gemm_256(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, nullptr, nullptr, 0, g.flags, 1.0f,
                             g.splits, g.tps, g.split_stride, stream);
-  else if (((g0.flags >> MH_GEMM_VARIANT_SHIFT) & 15) == 11)
-    rc = mh_launch_gemm_pp(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, nullptr, nullptr, 0, g.flags, 1.0f,
-                           g.splits, g.tps, g.split_stride, stream);
-  else if (((g0.flags >> MH_GEMM_VARIANT_SHIFT) & 15) == 13)
-    rc = mh_launch_gemm_stream(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, nullptr, nullptr, 0, g.flags, 1.0f,
-                               g.splits, g.tps, g.split_stride, stream_nfb(g.M, g.N, g.K), stream);
   else
     rc = launch_gemm<0, 2, 128, 2>(g, stream);
   if (rc) return rc;
@@ -532,35 +510,11 @@ static int big_tile_splits(int M, int N, int K, int tile_n) {
   return best;
 }
 
-// mid-M streaming kernel (gemm_stream.hip): fragments per workgroup and K slices come from its own planner
-static int stream_splits(int M, int N, int K) {
-  int nfb, s;
-  mh_gemm_stream_plan(M, N, K, 1, &nfb, &s);
-  return s;
-}
-
-static int stream_nfb(int M, int N, int K) {
-  int nfb, s;
-  mh_gemm_stream_plan(M, N, K, g_ws && (N % 4) == 0, &nfb, &s);
-  return nfb;
-}
-
-static int stream_enabled() {
-  static int on = -1;
-  if (on < 0) {
-    const char* e = getenv("MYRIAD_GEMM_STREAM");
-    on = (e && e[0] == '1') ? 1 : 0;              // off by default: at parity with the tile kernels, not ahead
-  }
-  return on;
-}
-
 // The automatic policy (flags carry no variant): which kernel runs and with how many K splits.
 //   kernel 0: gemv.hip weight streaming (M <= 16: decode)
 //   kernel 2: gemm_256.hip 256x256 tile, when it can put >= 128 workgroups on the chip with >= 1024 of K each
 //             (+20..26 % over the 128x128 kernel on the step's LLaMA / ViT shapes, cold weights,
 //             profiles/r01_gemm_256.md)
-//   kernel 3: gemm_stream.hip weight streaming with shared activation rows (16 < M <= 288); only with
-//             MYRIAD_GEMM_STREAM=1 -- measured at parity with kernels 1 / 2 on the batch-1 step, so not the default
 //   kernel 1: the 128x128 kernel for everything smaller -- it co-schedules two workgroups per CU and so hides its
 //             own prologue / store tail, which the one-workgroup-per-CU 256x256 kernel cannot
 static void gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits) {
@@ -569,11 +523,6 @@ static void gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits) 
   if (M <= 16 && !(flags & (MH_GEMM_REGSTAGE | MH_GEMM_GELU))) { *kernel = 0; return; }
   if (flags & MH_GEMM_REGSTAGE) return;
   const bool can_split = g_ws && (N % 4) == 0;
-  if (M <= 288 && (N % 4) == 0 && stream_enabled()) {
-    int s = can_split ? stream_splits(M, N, K) : 1;
-    while (s > 1 && (size_t)s * M * N * sizeof(float) > g_ws_bytes) --s;
-    *kernel = 3; *splits = s; return;
-  }
   if (M > 128) {
     const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
     int s = can_split ? big_tile_splits(M, N, K, 256) : 1;
@@ -608,25 +557,13 @@ extern "C" int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
       return mh_launch_gemv(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, (flags & MH_GEMM_OUT_F32) ? 1 : 0,
                             alpha, stream);
     if (kernel == 2) g.flags |= 12 << MH_GEMM_VARIANT_SHIFT;
-    if (kernel == 3) {
-      // 16-byte epilogue accesses: an oddly aligned bias / residual view goes to the 128x128 kernel instead
-      if (((uintptr_t)bias & 15) || ((uintptr_t)residual & 15)) splits = 1;
-      else g.flags |= 13 << MH_GEMM_VARIANT_SHIFT;
-    }
     // the split-K reduce reads `residual` and writes C element-wise, so C may alias residual (in-place accumulate)
     return splits > 1 ? run_splitk(g, splits, ws_for(stream), stream) : dispatch(g, stream);
   }
   // forced variants (A/B tools): the 8-wave kernels still pick their own split count
-  if ((variant == 11 || variant == 12) && g_ws && (N % 4) == 0) {
-    const int best = big_tile_splits(M, N, K, variant == 12 ? 256 : 128);
+  if (variant == 12 && g_ws && (N % 4) == 0) {
+    const int best = big_tile_splits(M, N, K, 256);
     if (best > 1 && (size_t)best * M * N * sizeof(float) <= g_ws_bytes) return run_splitk(g, best, ws_for(stream), stream);
-  }
-  if (variant == 13) {
-    if (M > 288 || (N % 4) != 0 || ((uintptr_t)bias & 15) || ((uintptr_t)residual & 15)) return MH_ERR_UNSUPPORTED;
-    int s = g_ws ? stream_splits(M, N, K) : 1;
-    if (const char* e = getenv("MYRIAD_STREAM_SPLITS")) s = atoi(e) > 0 && g_ws ? atoi(e) : s;
-    while (s > 1 && (size_t)s * M * N * sizeof(float) > g_ws_bytes) --s;
-    if (s > 1) return run_splitk(g, s, ws_for(stream), stream);
   }
   return dispatch(g, stream);
 }
@@ -647,7 +584,6 @@ static int gemm_residual_norm(int norm, const void* A, int lda, const void* B, i
       (lda % 8) == 0 && (ldb % 8) == 0 && !(((uintptr_t)A | (uintptr_t)B | (uintptr_t)H) & 15)) {
     GemmArgs g = {A, lda, B, ldb, (void*)H, ldh, M, N, K, nullptr, residual, ldr, MH_GEMM_OUT_F32, 1.0f, 1, K / 64, 0L};
     if (kernel == 2) g.flags |= 12 << MH_GEMM_VARIANT_SHIFT;
-    if (kernel == 3) g.flags |= 13 << MH_GEMM_VARIANT_SHIFT;
     const int nt = K / 64;                          // the split count run_splitk will settle on
     int sp = splits > nt ? nt : splits;
     const int tps = (nt + sp - 1) / sp;
@@ -700,7 +636,6 @@ extern "C" int mh_gemm_rmsnorm_bwd(const void* A, int lda, const void* B, int ld
       !(((uintptr_t)A | (uintptr_t)B) & 15)) {
     GemmArgs g = {A, lda, B, ldb, (void*)dy_buf, N, M, N, K, nullptr, nullptr, 0, MH_GEMM_OUT_F32, 1.0f, 1, K / 64, 0L};
     if (kernel == 2) g.flags |= 12 << MH_GEMM_VARIANT_SHIFT;
-    if (kernel == 3) g.flags |= 13 << MH_GEMM_VARIANT_SHIFT;
     const int nt = K / 64;                          // the split count run_splitk will settle on
     int sp = splits > nt ? nt : splits;
     const int tps = (nt + sp - 1) / sp;
@@ -737,7 +672,6 @@ extern "C" int mh_gemm_attn_rope_bwd(const void* A, int lda, const void* Bw, int
       !(((uintptr_t)A | (uintptr_t)Bw) & 15)) {
     GemmArgs g = {A, lda, Bw, ldb, do_buf, N, M, N, K, nullptr, nullptr, 0, MH_GEMM_OUT_F32, 1.0f, 1, K / 64, 0L};
     if (kernel == 2) g.flags |= 12 << MH_GEMM_VARIANT_SHIFT;
-    if (kernel == 3) g.flags |= 13 << MH_GEMM_VARIANT_SHIFT;
     const int nt = K / 64;                          // the split count run_splitk will settle on
     int sp = splits > nt ? nt : splits;
     const int tps = (nt + sp - 1) / sp;
@@ -752,6 +686,54 @@ extern "C" int mh_gemm_attn_rope_bwd(const void* A, int lda, const void* Bw, int
   if (rc) return rc;
   return mh_launch_attn_rope_bwd(qkv, ld, o, ldo, do_buf, 1, 1, 0, N, lse, dqkv, pos, cos_tab, sin_tab, kv_len, B, H, S, D, scale,
                                  stream);
+}
+
+// ---- SiLU-gated MLP (modeling_llama.py:139-140) fused into the two GEMMs around it -------------------------------------------
+// The gate|up weight is held with its rows interleaved in blocks of 128 (llama.py builds it so): gu[M, 2I] =
+// [g 0..127 | u 0..127 | g 128..255 | ...].  When the policy runs the unsplit 256-column kernel the elementwise part rides
+// its epilogue (gemm_256.hip, MH_GEMM_SWIGLU_*); otherwise the GEMM and the block-layout silu kernel run back to back --
+// the same bits either way (g, u, dact are rounded to bf16 before the elementwise math in both forms).
+#define MH_GEMM_SWIGLU_FWD 16
+#define MH_GEMM_SWIGLU_BWD 32
+extern "C" int mh_silu_mul_fwd_blk(const void* gu, void* h, int M, int I, int blk, hipStream_t stream);
+extern "C" int mh_silu_mul_bwd_blk(const void* dh, const void* gu, void* dgu, int M, int I, int blk, hipStream_t stream);
+
+static bool swiglu_fusable(int M, int N, int K, int lda, int ldb, const void* A, const void* B) {
+  int kernel = 1, splits = 1;
+  gemm_plan(M, N, K, 0, &kernel, &splits);
+  static int off = -1;
+  if (off < 0) { const char* e = getenv("MYRIAD_SWIGLU_FUSED"); off = (e && e[0] == '0') ? 1 : 0; }
+  return !off && kernel == 2 && splits == 1 && (N % 128) == 0 && (K % 64) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 &&
+         !(((uintptr_t)A | (uintptr_t)B) & 15);
+}
+
+// gu[M, 2I] = X[M, K] . Wgu[2I, K]^T (bf16, saved for the backward) and act[M, I] = silu(g) * u
+extern "C" int mh_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int ldw, void* gu, int ldgu, void* act, int ldact,
+                                  int M, int I, int K, hipStream_t stream) {
+  if (M <= 0 || I <= 0) return MH_OK;
+  if (!gu || !act || (I % 128) || (ldgu % 8) || (ldact % 8) || ldgu < 2 * I || ldact < I) return MH_ERR_ARG;
+  if (swiglu_fusable(M, 2 * I, K, ldx, ldw, X, Wgu))
+    return mh_launch_gemm_256(X, ldx, Wgu, ldw, gu, ldgu, M, 2 * I, K, nullptr, nullptr, 0, MH_GEMM_SWIGLU_FWD, 1.0f, 1, K / 64,
+                              0L, stream, act, ldact);
+  if (ldgu != 2 * I || ldact != I) return MH_ERR_ARG;         // the elementwise kernels take dense rows
+  const int rc = mh_gemm_bf16_nt(X, ldx, Wgu, ldw, gu, ldgu, M, 2 * I, K, nullptr, nullptr, 0, 0, 1.0f, stream);
+  if (rc) return rc;
+  return mh_silu_mul_fwd_blk(gu, act, M, I, 128, stream);
+}
+
+// dgu[M, 2I] = silu_mul_bwd(dact, gu) with dact[M, I] = dH[M, K] . WdT[I, K]^T (the down projection's dgrad); dact_buf [M, I]
+// bf16 is scratch for the unfused case
+extern "C" int mh_gemm_swiglu_bwd(const void* dH, int lddh, const void* WdT, int ldw, const void* gu, int ldgu, void* dgu,
+                                  int lddgu, void* dact_buf, int M, int I, int K, hipStream_t stream) {
+  if (M <= 0 || I <= 0) return MH_OK;
+  if (!gu || !dgu || (I % 128) || (ldgu % 8) || (lddgu % 8) || ldgu < 2 * I || lddgu < 2 * I) return MH_ERR_ARG;
+  if (swiglu_fusable(M, I, K, lddh, ldw, dH, WdT))
+    return mh_launch_gemm_256(dH, lddh, WdT, ldw, dgu, lddgu, M, I, K, nullptr, nullptr, 0, MH_GEMM_SWIGLU_BWD, 1.0f, 1, K / 64,
+                              0L, stream, const_cast<void*>(gu), ldgu);
+  if (!dact_buf || ldgu != 2 * I || lddgu != 2 * I) return MH_ERR_ARG;
+  const int rc = mh_gemm_bf16_nt(dH, lddh, WdT, ldw, dact_buf, I, M, I, K, nullptr, nullptr, 0, 0, 1.0f, stream);
+  if (rc) return rc;
+  return mh_silu_mul_bwd_blk(dact_buf, gu, dgu, M, I, 128, stream);
 }
 
 // ---- explicit split-K entry (wgrad of the conv stem: M,N small, K huge); caller passes the scratch ----

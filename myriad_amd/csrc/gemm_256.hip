@@ -44,6 +44,15 @@
 
 #define MH_GEMM_OUT_F32 1
 #define MH_GEMM_GELU 2
+// SiLU-gated MLP fused into the epilogue (modeling_llama.py:139-140).  The gate|up weight rows are interleaved in blocks of
+// 128 ([g 0..127 | u 0..127 | g 128..255 | ...]) so one 256-column tile holds 128 gate columns and their 128 up columns.
+//   SWIGLU_FWD: C = gu (bf16, kept for the backward) and aux[M, N/2] = silu(g) * u; waves wc and wc + 2 hold g and u of the
+//               same (rows, columns), exchanged through the epilogue's LDS slices.
+//   SWIGLU_BWD: the tile is dact = dh . W_down; aux = gu [M, 2N] (interleaved), C = dgu [M, 2N]:
+//               dg = dact * u * (s + g s (1 - s)), du = dact * g s, s = sigmoid(g); dact itself is never stored.
+// Both round g, u and dact to bf16 before the elementwise math, exactly as the separate silu_mul kernels see them.
+#define MH_GEMM_SWIGLU_FWD 16
+#define MH_GEMM_SWIGLU_BWD 32
 
 typedef __attribute__((address_space(3))) void lds_void_t;
 typedef const __attribute__((address_space(1))) void gbl_void_t;
@@ -86,7 +95,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(const bf16_t* __restri
                                                           void* Cv, const float* __restrict__ bias, const float* res,
                                                           int M, int N, int K, int lda, int ldb, int ldc, int ldr,
                                                           int flags, float alpha, int tiles_m, int kt_per_split,
-                                                          long split_stride, long long* trace) {
+                                                          long split_stride, long long* trace, void* aux, int ldaux) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // [4 stages][A 16K | B 16K]; reused by the epilogue
   G2_LIFE(0)
   const int tid = threadIdx.x;
@@ -204,6 +213,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(const bf16_t* __restri
   // residual are applied on the way out, where a lane holds 4 consecutive columns of one row.
   const bool out_f32 = flags & MH_GEMM_OUT_F32;
   const bool do_gelu = flags & MH_GEMM_GELU;
+  const bool sw_fwd = flags & MH_GEMM_SWIGLU_FWD, sw_bwd = flags & MH_GEMM_SWIGLU_BWD;
   char* ep = smem + wave * 16384;                      // [64 rows][16 chunks of 16 B], chunk ^= row & 15
   const int er = lane >> 4, ec = lane & 15;            // write-out: 4 rows per pass, lane owns columns ec*4 .. +3
   const int ncol = n0 + wc * 64 + ec * 4;
@@ -221,6 +231,66 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(const bf16_t* __restri
       }
     }
     // the slice is private to the wave: program order + the compiler's lgkmcnt wait are the only ordering needed
+    if (sw_bwd) {
+      // dact (this wave: 64 rows x 64 columns of the [M, N] product) -> dg, du at the interleaved positions of gu / dgu
+      const int r8 = lane >> 3, c8 = lane & 7;
+      const int nc = n0 + wc * 64 + c8 * 8;                       // dact column
+      const long gcol = (long)(nc >> 7) * 256 + (nc & 127);       // gate column in the interleaved [M, 2N] layout (up: + 128)
+      const bf16_t* gu_in = reinterpret_cast<const bf16_t*>(aux);
+      bf16_t* dgu = reinterpret_cast<bf16_t*>(Cv);
+#pragma unroll 4
+      for (int p = 0; p < 8; ++p) {
+        const int row = p * 8 + r8;
+        const int m = m0 + grp * 128 + h * 64 + row;
+        const float4_t va = *reinterpret_cast<const float4_t*>(ep + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
+        const float4_t vb = *reinterpret_cast<const float4_t*>(ep + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
+        if (m >= M || nc >= N) continue;
+        const float v[8] = {va[0], va[1], va[2], va[3], vb[0], vb[1], vb[2], vb[3]};
+        const short8_t g8 = *reinterpret_cast<const short8_t*>(gu_in + (size_t)m * ldaux + gcol);
+        const short8_t u8 = *reinterpret_cast<const short8_t*>(gu_in + (size_t)m * ldaux + gcol + 128);
+        short8_t og, ou;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float gv = bf2f((bf16_t)g8[e]), uv = bf2f((bf16_t)u8[e]), dv = bf2f(f2bf(v[e]));
+          const float sg = 1.f / (1.f + __expf(-gv));
+          const float silu = gv * sg;
+          og[e] = (short)f2bf(dv * uv * (sg + silu * (1.f - sg)));
+          ou[e] = (short)f2bf(dv * silu);
+        }
+        *reinterpret_cast<short8_t*>(dgu + (size_t)m * ldc + gcol) = og;
+        *reinterpret_cast<short8_t*>(dgu + (size_t)m * ldc + gcol + 128) = ou;
+      }
+      continue;
+    }
+    if (sw_fwd) {
+      // every wave of the group has written its slice; wave (grp, wc) pairs with (grp, wc ^ 2): columns wc & 1, rows
+      // 0..31 (wc < 2) or 32..63 (wc >= 2) of this 64-row half -> act = silu(g) * u, 32 rows x 64 columns per wave
+      __syncthreads();
+      const int r8 = lane >> 3, c8 = lane & 7;
+      const char* sg_ = smem + (grp * 4 + (wc & 1)) * 16384;       // gate slice
+      const char* su_ = smem + (grp * 4 + (wc & 1) + 2) * 16384;   // up slice
+      bf16_t* act = reinterpret_cast<bf16_t*>(aux);
+      const int ac = (n0 >> 1) + (wc & 1) * 64 + c8 * 8;           // act column (natural order)
+#pragma unroll 4
+      for (int p = 0; p < 4; ++p) {
+        const int row = (wc >> 1) * 32 + p * 8 + r8;
+        const int m = m0 + grp * 128 + h * 64 + row;
+        const int o0 = row * 256 + (((2 * c8) ^ (row & 15)) << 4), o1 = row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4);
+        const float4_t ga = *reinterpret_cast<const float4_t*>(sg_ + o0), gb = *reinterpret_cast<const float4_t*>(sg_ + o1);
+        const float4_t ua = *reinterpret_cast<const float4_t*>(su_ + o0), ub = *reinterpret_cast<const float4_t*>(su_ + o1);
+        if (m >= M || ac >= (N >> 1)) continue;
+        const float gg[8] = {ga[0], ga[1], ga[2], ga[3], gb[0], gb[1], gb[2], gb[3]};
+        const float uu[8] = {ua[0], ua[1], ua[2], ua[3], ub[0], ub[1], ub[2], ub[3]};
+        short8_t o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float gv = bf2f(f2bf(gg[e])), uv = bf2f(f2bf(uu[e]));
+          o[e] = (short)f2bf(gv / (1.f + __expf(-gv)) * uv);
+        }
+        *reinterpret_cast<short8_t*>(act + (size_t)m * ldaux + ac) = o;
+      }
+      // fall through: the bf16 store path below writes this wave's own gu columns
+    }
     if (!out_f32 && (ldc & 7) == 0) {
       // bf16 output: 16-B stores, 8 lanes cover one 128-B row, 8 rows per pass (half the store instructions of the
       // 8-B form; the store tail is issue-bound, not bandwidth-bound)
@@ -267,6 +337,7 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(const bf16_t* __restri
           }
         }
       }
+      if (sw_fwd) __syncthreads();                     // the partner has read this slice before the next half overwrites it
       continue;
     }
 #pragma unroll 4
@@ -319,7 +390,12 @@ extern "C" void mhdbg_set_gemm256_trace(void* p) { g2_trace = (long long*)p; }  
 // tps / split_stride as in gemm.hip (tps in 64-deep K tiles)
 int mh_launch_gemm_256(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                        const float* bias, const float* residual, int ldr, int flags, float alpha, int splits, int tps,
-                       long split_stride, hipStream_t stream) {
+                       long split_stride, hipStream_t stream, void* aux, int ldaux) {
+  if (flags & (MH_GEMM_SWIGLU_FWD | MH_GEMM_SWIGLU_BWD)) {
+    // one 256-column tile = whole 128-column blocks; 16-byte rows; the fused forms never split K or take bias / residual
+    if (!aux || splits != 1 || bias || residual || (flags & (MH_GEMM_OUT_F32 | MH_GEMM_GELU)) || (ldc & 7) || (ldaux & 7) || (N & 127))
+      return MH_ERR_ARG;
+  }
   const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
   const size_t shmem = G2_NST * G2_STAGE;   // 128 KiB -> one 8-wave workgroup per CU
   static bool attr_set = false;
@@ -331,10 +407,10 @@ int mh_launch_gemm_256(const void* A, int lda, const void* B, int ldb, void* C, 
   const dim3 grid(tiles_m * tiles_n, splits), block(512);
   if (g2_trace)
     hipLaunchKernelGGL((gemm_256_kernel<true>), grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)B, C, bias,
-                       residual, M, N, K, lda, ldb, ldc, ldr, flags, alpha, tiles_m, tps * 2, split_stride, g2_trace);
+                       residual, M, N, K, lda, ldb, ldc, ldr, flags, alpha, tiles_m, tps * 2, split_stride, g2_trace, aux, ldaux);
   else
     hipLaunchKernelGGL((gemm_256_kernel<false>), grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)B, C, bias,
-                       residual, M, N, K, lda, ldb, ldc, ldr, flags, alpha, tiles_m, tps * 2, split_stride, nullptr);
+                       residual, M, N, K, lda, ldb, ldc, ldr, flags, alpha, tiles_m, tps * 2, split_stride, nullptr, aux, ldaux);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

@@ -48,15 +48,17 @@ class LlamaHIP:
             wq, wk, wv = (sd[lp + f"self_attn.{n}_proj.weight"] for n in "qkv")
             wqkv = _bf(torch.cat([wq, wk, wv], 0), self.dev)
             wo = _bf(sd[lp + "self_attn.o_proj.weight"], self.dev)
-            # intermediate size padded to a multiple of 64 (GEMM K granule); zero rows/cols are exact no-ops
+            # intermediate size padded to a multiple of 128 (the gate|up interleave block; also the GEMM K granule): zero
+            # rows/cols are exact no-ops.  gate and up rows are interleaved in blocks of 128 so that one 256-column tile of the
+            # gate|up GEMM holds g and u of the same columns and silu(g)*u rides its epilogue (ops.gemm_swiglu_fwd)
             wg, wu, wdn = sd[lp + "mlp.gate_proj.weight"], sd[lp + "mlp.up_proj.weight"], sd[lp + "mlp.down_proj.weight"]
             I0 = wg.shape[0]
-            Ip = ops.round_up(I0, 64)
+            Ip = ops.round_up(I0, ops.SWIGLU_BLK)
             if Ip != I0:
                 z = torch.zeros(Ip - I0, wg.shape[1], dtype=wg.dtype, device=wg.device)
                 wg, wu = torch.cat([wg, z], 0), torch.cat([wu, z], 0)
                 wdn = torch.cat([wdn, torch.zeros(wdn.shape[0], Ip - I0, dtype=wdn.dtype, device=wdn.device)], 1)
-            wgu = _bf(torch.cat([wg, wu], 0), self.dev)
+            wgu = ops.interleave_gate_up(_bf(wg, self.dev), _bf(wu, self.dev))
             wd = _bf(wdn, self.dev)
             L = dict(wqkv=wqkv, wo=wo, wgu=wgu, wd=wd,
                      ln1=_f32(sd[lp + "input_layernorm.weight"], self.dev),
@@ -157,8 +159,7 @@ class LlamaHIP:
                 o, lse = ops.attn_fwd(q3[:, :, :W], q3[:, :, W:2 * W], q3[:, :, 2 * W:], H, hd, scale, causal=True,
                                       kv_len=kv_len)
             h2, xn2 = ops.gemm_residual_rmsnorm(o.view(M, W), L["wo"], h, L["ln2"], self.eps)
-            gu = ops.gemm(xn2, L["wgu"])                                    # [M, 2I]
-            act = ops.silu_mul_fwd(gu)
+            gu, act = ops.gemm_swiglu_fwd(xn2, L["wgu"])                    # [M, 2I] (interleaved g|u blocks), [M, I]
             if li + 1 < len(self.layers):
                 h3, xn = ops.gemm_residual_rmsnorm(act, L["wd"], h2, self.layers[li + 1]["ln1"], self.eps,
                                                    y_out=norm_target(li + 1))
@@ -207,8 +208,7 @@ class LlamaHIP:
         n_layers = len(self.layers)
         for ri, (L, (h_in, qkv, o, lse, h2, gu, lsave)) in enumerate(zip(reversed(self.layers), reversed(sv["layers"]))):
             li = n_layers - 1 - ri
-            dact = ops.gemm(dh_b, L["wdT"])                                 # [M, I] bf16
-            dgu = ops.silu_mul_bwd(dact, gu)
+            dgu = ops.gemm_swiglu_bwd(dh_b, L["wdT"], gu)                   # down dgrad + gate backward: [M, 2I]
             # gate|up dgrad [M, D] and the post-attention norm's backward in one call (split-K slabs summed in the norm kernel)
             dh2, dh2_b = ops.gemm_rmsnorm_bwd(dgu, L["wguT"], h2, L["ln2"], self.eps, dres=dh)
             q3 = qkv.view(B, S, 3 * W)
@@ -278,7 +278,7 @@ class LlamaHIP:
                                     kv_len=kvlen_dev, need_lse=False)
             h2 = lin(li, "wo", o.view(M, W), residual=h, out_dtype=F32)
             xn2 = ops.rmsnorm_fwd(h2, L["ln2"], self.eps)
-            act = ops.silu_mul_fwd(lin(li, "wgu", xn2))
+            act = ops.silu_mul_fwd_blk(lin(li, "wgu", xn2))
             h = lin(li, "wd", act, residual=h2, out_dtype=F32)
         return h
 

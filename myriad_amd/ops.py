@@ -156,7 +156,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, b
     return out
 
 
-GEMM_KERNEL_NAMES = {0: "gemv_kernel", 1: "gemm_nt_kernel", 2: "gemm_256_kernel", 3: "gemm_stream_kernel"}
+GEMM_KERNEL_NAMES = {0: "gemv_kernel", 1: "gemm_nt_kernel", 2: "gemm_256_kernel"}
 
 
 def gemm_plan(M: int, N: int, K: int, out_f32: bool = False, gelu: bool = False):
@@ -414,6 +414,53 @@ def silu_mul_bwd(dh: torch.Tensor, gu: torch.Tensor):
     M, I2 = gu.shape
     dgu = torch.empty_like(gu)
     _lib.check(_L().mh_silu_mul_bwd(_p(dh), _p(gu), _p(dgu), M, I2 // 2, _s()), "mh_silu_mul_bwd")
+    return dgu
+
+
+SWIGLU_BLK = 128      # gate / up interleave of the fused MLP GEMMs (csrc/gemm.hip mh_gemm_swiglu_*)
+
+
+def interleave_gate_up(wg: torch.Tensor, wu: torch.Tensor, blk: int = SWIGLU_BLK) -> torch.Tensor:
+    """[I, D] gate and up weights -> [2I, D] with rows [g 0..blk-1 | u 0..blk-1 | g blk.. | ...] (I % blk == 0)."""
+    I, D = wg.shape
+    if I % blk:
+        raise _lib.MyriadHipError(f"interleave_gate_up: I={I} is not a multiple of {blk}")
+    return torch.stack([wg.reshape(I // blk, blk, D), wu.reshape(I // blk, blk, D)], 1).reshape(2 * I, D).contiguous()
+
+
+def silu_mul_fwd_blk(gu: torch.Tensor, blk: int = SWIGLU_BLK):
+    M, I2 = gu.shape
+    h = torch.empty((M, I2 // 2), dtype=BF16, device=gu.device)
+    _lib.check(_L().mh_silu_mul_fwd_blk(_p(gu), _p(h), M, I2 // 2, blk, _s()), "mh_silu_mul_fwd_blk")
+    return h
+
+
+def gemm_swiglu_fwd(x: torch.Tensor, wgu: torch.Tensor):
+    """(gu [M, 2I] bf16 in the interleaved layout, act [M, I] = silu(g) * u): the gate|up projection with the gated product
+    in its epilogue (separate launches, same bits, when the policy does not run the fused kernel)."""
+    _chk2d(x, BF16, "gemm_swiglu_fwd.x")
+    _chk2d(wgu, BF16, "gemm_swiglu_fwd.wgu")
+    M, K = x.shape
+    I = wgu.shape[0] // 2
+    gu = torch.empty((M, 2 * I), dtype=BF16, device=x.device)
+    act = torch.empty((M, I), dtype=BF16, device=x.device)
+    rc = _L().mh_gemm_swiglu_fwd(_p(x), x.stride(0), _p(wgu), wgu.stride(0), _p(gu), 2 * I, _p(act), I, M, I, K, _s())
+    _lib.check(rc, f"mh_gemm_swiglu_fwd M={M} I={I} K={K}")
+    return gu, act
+
+
+def gemm_swiglu_bwd(dh: torch.Tensor, wdT: torch.Tensor, gu: torch.Tensor):
+    """dgu [M, 2I] = silu_mul_bwd(dh @ wdT^T, gu): the down projection's dgrad with the gate backward in its epilogue."""
+    _chk2d(dh, BF16, "gemm_swiglu_bwd.dh")
+    _chk2d(wdT, BF16, "gemm_swiglu_bwd.wdT")
+    _chk2d(gu, BF16, "gemm_swiglu_bwd.gu")
+    M, K = dh.shape
+    I = wdT.shape[0]
+    dgu = torch.empty_like(gu)
+    dact = torch.empty((M, I), dtype=BF16, device=dh.device)
+    rc = _L().mh_gemm_swiglu_bwd(_p(dh), dh.stride(0), _p(wdT), wdT.stride(0), _p(gu), gu.stride(0), _p(dgu), dgu.stride(0),
+                                 _p(dact), M, I, K, _s())
+    _lib.check(rc, f"mh_gemm_swiglu_bwd M={M} I={I} K={K}")
     return dgu
 
 

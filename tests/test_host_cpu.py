@@ -125,6 +125,50 @@ def test_gradient_allreduce_world2_gloo():
     assert torch.equal(got[0][1], got[1][1])
 
 
+def _dp_flags_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    specs = [("expert_adaptor.conv1.weight", (4, 8), (4, 8)), ("VETokenizer.base_prompts", (9, 16), (9, 16)),
+             ("VEInstructor.meta_net.0.bias", (4,), (4,)), ("llama_model.base_model.model.model.layers.0.self_attn.q_proj.lora_A.default.weight", (8, 16), (8, 16))]
+    st = ParamStore(specs, "cpu")
+    torch.manual_seed(7 + rank)
+    st.flat_g.copy_(torch.randn(st.total))
+    # per-rank random prompt stage (myriad.py:378, seeds differ per rank): rank 0 uses the tokenizer, rank 1 the instructor;
+    # nobody uses LoRA this step
+    used = {"expert_adaptor", "VETokenizer"} if rank == 0 else {"expert_adaptor", "VEInstructor"}
+    st.used.copy_(torch.tensor([1.0 if m in used else 0.0 for m in st.modules]))
+    dp = DataParallel(device=None)
+    dp.allreduce(st.flat_g_comm)                       # ONE exchange carries gradients and use flags
+    q.put((rank, st.modules, st.used.clone(), st.flat_g.clone()))
+    dp.barrier()
+    dist.destroy_process_group()
+
+
+def test_module_use_flags_ride_the_gradient_allreduce_world2_gloo():
+    """The gated AdamW (mh_adamw_gated) must skip a module only when NO rank used it (DDP leaves the grad of a globally unused
+    parameter None and torch's AdamW skips it; a module used on one rank gets that rank's gradient / world).  The per-module
+    use flags sit at the tail of the flat gradient buffer, so the data-parallel sum delivers the global use count."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_flags_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = {}
+    for _ in range(2):
+        r, modules, used, grad = q.get(timeout=120)
+        got[r] = (modules, used, grad)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    modules = got[0][0]
+    assert modules == ["expert_adaptor", "VETokenizer", "VEInstructor", "lora"]
+    for r in range(2):
+        assert got[r][1].tolist() == [2.0, 1.0, 1.0, 0.0]      # used on both / one / one / no rank -> only LoRA is skipped
+    assert torch.equal(got[0][2], got[1][2])
+
+
 def test_gemm_policy_for_the_steps_shapes():
     """mh_gemm_plan is host-only logic (no launch): which kernel / how many K splits the library picks.  Pins the
     policy for the shapes of the fine-tune step (B*S = 1184 LLaMA rows, 2056 ViT rows) and the decode token."""

@@ -143,44 +143,6 @@ def test_decode_kernel_on_the_packed_weight_copy_is_bit_identical(M, N, K):
         ops.gemv_packed(bf(rnd(17, K)).to(DEV), pw)
 
 
-@pytest.mark.parametrize("ws", [True, False])
-@pytest.mark.parametrize("M,N,K", [(148, 4096, 4096), (148, 12352, 4160), (257, 1408, 6144), (17, 1000, 11008), (288, 4224, 1408),
-                                   (60, 32000, 4096), (148, 136, 64), (33, 72, 448)])
-def test_mid_m_weight_streaming_gemm(M, N, K, ws):
-    """16 < M <= 288 (the batch-1 step, prefill) forced onto gemm_stream.hip (variant 13): 256 weight rows per workgroup, weights
-    straight to registers, activation rows through the LDS ring; with a workspace K is split and the epilogue moves to the
-    reduce pass.  Every epilogue, strided operands, ragged N and the 1-step / tail-step K loops."""
-    if ws:
-        ops.ensure_workspace(DEV)
-    else:
-        ops.drop_workspace()
-    try:
-        a_full = bf(rnd(M, K + 64, seed=51)).to(DEV)
-        a = a_full[:, :K]
-        b = bf(rnd(N, K, seed=52) * 0.05 + torch.arange(N)[:, None] * 1e-4).to(DEV)
-        bias = rnd(N, seed=53).to(DEV)
-        res = rnd(M, N, seed=54).to(DEV)
-        ref = a.float() @ b.float().T
-        tol = 2e-5 * math.sqrt(K) + 1e-5
-        assert relerr(ops.gemm(a, b, out_dtype=torch.float32, variant=13), ref) < tol
-        assert relerr(ops.gemm(a, b, variant=13).float(), ref) < 6e-3
-        o = ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32, alpha=0.5, variant=13)
-        assert relerr(o, 0.5 * ref + bias + res) < tol
-        og = ops.gemm(a, b, bias=bias, gelu=True, variant=13)
-        assert relerr(og.float(), F.gelu(ref + bias)) < 6e-3
-        acc = res.clone()
-        ops.gemm(a, b, out=acc, residual=acc, variant=13)
-        assert relerr(acc, ref + res) < tol
-        wide = torch.zeros(M, N + 72, dtype=torch.bfloat16, device=DEV)
-        ops.gemm(a, b, out=wide[:, 8:8 + N], variant=13)
-        assert relerr(wide[:, 8:8 + N].float(), ref) < 6e-3
-        assert wide[:, :8].abs().max() == 0 and wide[:, 8 + N:].abs().max() == 0
-        # against the 128x128 kernel on the same operands
-        assert relerr(ops.gemm(a, b, out_dtype=torch.float32, variant=13), ops.gemm(a, b, out_dtype=torch.float32, variant=1)) < 1e-4
-    finally:
-        ops.ensure_workspace(DEV)
-
-
 @pytest.mark.parametrize("M,N,K", [(1184, 4096, 4096), (1184, 4096, 11008), (300, 512, 256), (2056, 1408, 6144), (148, 4096, 11008)])
 def test_gemm_residual_rmsnorm_is_bit_identical_to_two_launches(M, N, K):
     """Split-K reduce + residual add + RMSNorm in one kernel (split shapes) or GEMM then norm (the rest): same bits."""
@@ -332,6 +294,41 @@ def test_attention_online_softmax_spike():
 
     ref = attn_ref(heads(q), heads(k), heads(v), D ** -0.5, False, None, None).transpose(1, 2).reshape(B, S, H * D)
     assert relerr(o.float(), ref) < 1.5e-2
+
+
+@pytest.mark.parametrize("M,I,K", [(1184, 11008, 4096), (300, 256, 128), (148, 1024, 512)])
+def test_swiglu_fused_into_the_mlp_gemms(M, I, K):
+    """mh_gemm_swiglu_fwd/bwd (SiLU-gated product in the gate|up GEMM's epilogue, its backward in the down dgrad's) against
+    an fp32 torch model of LlamaMLP (modeling_llama.py:139-140) and bit-for-bit against GEMM + silu kernels."""
+    ops.ensure_workspace(torch.device(DEV))
+    x = bf(rnd(M, K, seed=71, scale=0.5)).to(DEV)
+    wg = bf(rnd(I, K, seed=72, scale=0.05)).to(DEV)
+    wu = bf(rnd(I, K, seed=73, scale=0.05) + torch.arange(I)[:, None] * 1e-5).to(DEV)
+    wgu = ops.interleave_gate_up(wg, wu)
+    gu, act = ops.gemm_swiglu_fwd(x, wgu)
+    g_ref, u_ref = x.float() @ wg.float().T, x.float() @ wu.float().T
+    blk = ops.SWIGLU_BLK
+    gu3 = gu.float().view(M, I // blk, 2, blk)
+    assert relerr(gu3[:, :, 0].reshape(M, I), g_ref) < 6e-3 and relerr(gu3[:, :, 1].reshape(M, I), u_ref) < 6e-3
+    assert relerr(act.float(), F.silu(g_ref) * u_ref) < 1.5e-2
+    gu2 = ops.gemm(x, wgu)
+    assert torch.equal(gu, gu2) and torch.equal(act, ops.silu_mul_fwd_blk(gu2))
+    # backward: dh [M, D] against the down projection's transposed weight [I, D]
+    D = 256 if K <= 512 else 4096
+    dh = bf(rnd(M, D, seed=74, scale=0.1)).to(DEV)
+    wdT = bf(rnd(I, D, seed=75, scale=0.05)).to(DEV)
+    dgu = ops.gemm_swiglu_bwd(dh, wdT, gu)
+    dact = ops.gemm(dh, wdT)
+    want = torch.empty_like(gu)
+    from myriad_amd import _lib
+    _lib.check(_lib.load().mh_silu_mul_bwd_blk(dact.data_ptr(), gu.data_ptr(), want.data_ptr(), M, I, blk,
+                                               torch.cuda.current_stream().cuda_stream), "mh_silu_mul_bwd_blk")
+    assert torch.equal(dgu, want)
+    g32 = gu3[:, :, 0].reshape(M, I).clone().requires_grad_(True)
+    u32 = gu3[:, :, 1].reshape(M, I).clone().requires_grad_(True)
+    (F.silu(g32) * u32 * (dh.float() @ wdT.float().T)).sum().backward()
+    d3 = dgu.float().view(M, I // blk, 2, blk)
+    assert relerr(d3[:, :, 0].reshape(M, I), g32.grad) < 2e-2 and relerr(d3[:, :, 1].reshape(M, I), u32.grad) < 2e-2
 
 
 def _rope_tables(D, max_pos=256):

@@ -106,17 +106,60 @@ class GemmProbe:
                 return out
             return f
 
+        def timed_mlp(orig, which):
+            # SiLU-gated MLP GEMMs (mh_gemm_swiglu_*).  Default: the GEMM and the silu kernel are two launches -- issued here as
+            # the same two C calls so the event pair holds the GEMM alone.  MYRIAD_SWIGLU_FUSED=1: ONE launch of the 256-column
+            # kernel with the elementwise part in its epilogue.
+            one_launch = os.environ.get("MYRIAD_SWIGLU_FUSED", "0") == "1"
+
+            def f(a, b, *args, **kw):
+                if not one_launch:
+                    if which == "fwd":
+                        gu = timed(a, b)
+                        return gu, ops.silu_mul_fwd_blk(gu)
+                    return ops.silu_mul_bwd_blk(timed(a, b), args[0])
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = orig(a, b, *args, **kw)
+                e1.record()
+                shp = (a.shape[0], b.shape[0], a.shape[1])
+                self.records.append((e0, e1, 2.0 * shp[0] * shp[1] * shp[2], shp))
+                # bytes: operands + gu out (+ act out) / operands + gu in + dgu out
+                extra = shp[0] * shp[1] * (2 + 1) if which == "fwd" else shp[0] * shp[1] * (4 + 4)
+                self.bytes[shp] = self.bytes.get(shp, 0.0) + 2.0 * (shp[0] + shp[1]) * shp[2] + extra
+                return out
+            return f
+
+        def timed_attn(orig):
+            # o_proj dgrad + the attention backward that sums its split-K slabs (mh_gemm_attn_rope_bwd): GEMM + one more launch
+            def f(a, b, *args, **kw):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                out = orig(a, b, *args, **kw)
+                e1.record()
+                shp = (a.shape[0], b.shape[0], a.shape[1])
+                self.records.append((e0, e1, 2.0 * shp[0] * shp[1] * shp[2], shp))
+                self.fused.add(shp)
+                self.bytes[shp] = self.bytes.get(shp, 0.0) + 2.0 * (shp[0] + shp[1]) * shp[2] + shp[0] * shp[1] * 4
+                return out
+            return f
+
         self.fused = set()
-        self.orig_fused = (ops.gemm_residual_rmsnorm, ops.gemm_residual_layernorm, ops.gemm_rmsnorm_bwd)
+        self.orig_fused = (ops.gemm_residual_rmsnorm, ops.gemm_residual_layernorm, ops.gemm_rmsnorm_bwd, ops.gemm_swiglu_fwd,
+                           ops.gemm_swiglu_bwd, ops.gemm_attn_rope_bwd)
         ops.gemm = timed                     # modules call ops.* through the module attribute, so patching ops is enough
         ops.gemm_residual_rmsnorm = timed_fused(self.orig_fused[0])
         ops.gemm_residual_layernorm = timed_fused(self.orig_fused[1])
         ops.gemm_rmsnorm_bwd = timed_fused(self.orig_fused[2])   # dgrad Linear + the norm backward that reads it
+        ops.gemm_swiglu_fwd = timed_mlp(self.orig_fused[3], "fwd")
+        ops.gemm_swiglu_bwd = timed_mlp(self.orig_fused[4], "bwd")
+        ops.gemm_attn_rope_bwd = timed_attn(self.orig_fused[5])
         return self
 
     def __exit__(self, *exc):
         self.ops.gemm = self.orig
-        self.ops.gemm_residual_rmsnorm, self.ops.gemm_residual_layernorm, self.ops.gemm_rmsnorm_bwd = self.orig_fused
+        (self.ops.gemm_residual_rmsnorm, self.ops.gemm_residual_layernorm, self.ops.gemm_rmsnorm_bwd, self.ops.gemm_swiglu_fwd,
+         self.ops.gemm_swiglu_bwd, self.ops.gemm_attn_rope_bwd) = self.orig_fused
 
     def summary(self):
         torch.cuda.synchronize()
@@ -191,7 +234,7 @@ def cpu_baseline(arch: str, stage: int, cfg: dict, budget_note: str = "") -> dic
     loss = clock("llm_f", lambda: R.llama_causal_lm(sd, emb, attn, labels, cfg["llm_heads"])[0])
     clock("bwd_all", lambda: loss.backward())
     # backward time is attributed proportionally to forward time of the differentiable parts
-    f_parts = {k: v for k, v in t.items() if k not in ("vit", "bwd_all")}
+    f_parts = {k: v for k, v in t.items() if k not in ("vit", "bwd_all", "adamw_scaled")}
     fsum = sum(f_parts.values())
     scale = dict(vit=cfg["vit_depth"] / kv, qf_f=cfg["qf_layers"] / kq, llm_f=cfg["llm_layers"] / kl, ve_ins_f=1.0,
                  ve_tok_f=1.0)
@@ -199,7 +242,16 @@ def cpu_baseline(arch: str, stage: int, cfg: dict, budget_note: str = "") -> dic
     for k, v in f_parts.items():
         total += (v + t["bwd_all"] * v / fsum) * scale[k]
     n_train = sum(sd[k].numel() for k in train)
-    total += n_train * 28 / 5e9   # AdamW on the host at ~5 GB/s effective (measured class of stream rate on one socket)
+    # AdamW: the oracle's own update timed on a 16 M-element slice of the host buffers, scaled to the trainable count
+    ns = 1 << 24
+    pp, gg, mm, vv = (torch.randn(ns) for _ in range(4))
+    vv.abs_()
+    R.adamw_step(pp, gg, mm, vv, 1, 1e-4, 0.05)
+    t0 = time.perf_counter()
+    R.adamw_step(pp, gg, mm, vv, 2, 1e-4, 0.05)
+    t_adam = (time.perf_counter() - t0) * n_train / ns
+    t["adamw_scaled"] = t_adam
+    total += t_adam
     return dict(value=1.0 / total, unit="images/s", cores=nth, kind="port",
                 sample=f"oracle (CPU restatement pinned to the reference modules) fp32 B=1 {arch} stage {stage}: "
                        f"ViT {kv}/{cfg['vit_depth']} blocks, Q-Former {kq}/{cfg['qf_layers']}, LLaMA {kl}/"
@@ -305,17 +357,30 @@ def main():
             # HBM-side bytes per launch of the same kernel population come from separate rocprofv3 --pmc passes
             # (tools/pmc_traffic.sh -> profiles/r01_gemm256_traffic.json); null if that file is not for this kernel
             traffic = None
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm256_traffic.json")
+            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_gemm256_traffic.json")
+            if not os.path.exists(tpath):
+                tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm256_traffic.json")
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 if dom.split(":")[0] in tj.get("kernel", ""):
                     traffic = dict(bytes_per_launch=round(tj["traffic_bytes_per_launch"]), read=round(tj["read_bytes_per_launch"]),
                                    write=round(tj["write_bytes_per_launch"]),
                                    algorithmic_bytes_per_launch=round(dk["algorithmic_mb_per_launch"] * 1e6),
-                                   source="profiles/r01_gemm256_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)")
-            roof = dict(bound="mfma", kernel=dom.split(":")[0] + " (mh_gemm_bf16_nt, unsplit launches)", achieved=dk["tflops"],
+                                   source=f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)")
+            # the same kernel over ALL its launches of the step: split-K launches are timed as a pair (partial-product kernel +
+            # the reduce / norm / attention launch that consumes the slabs), so this is a lower bound on the kernel's own rate
+            dname = dom.split(":")[0]
+            allk = [v for k, v in pr.per_kernel.items() if k.startswith(dname + ":")]
+            all_ms = sum(v["total_ms"] for v in allk)
+            all_fl = sum(v["tflops"] * v["total_ms"] for v in allk)
+            dom_all = dict(launches=sum(v["launches"] for v in allk), total_ms=round(all_ms, 3),
+                           tflops=round(all_fl / all_ms, 1) if all_ms else None,
+                           frac=round(all_fl / all_ms / PEAK_BF16_TFLOPS, 4) if all_ms else None,
+                           note="split-K launches include the launch that sums their slabs")
+            roof = dict(bound="mfma", kernel=dname + " (unsplit launches: exactly one kernel per HIP-event pair)", achieved=dk["tflops"],
                         peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(dk["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=traffic,
-                        launches_per_step=dk["launches"], avg_launch_us=dk["avg_us"], per_kernel=pr.per_kernel,
+                        launches_per_step=dk["launches"], avg_launch_us=dk["avg_us"], all_launches_of_kernel=dom_all,
+                        per_kernel=pr.per_kernel,
                         all_gemm=dict(launches=gs["launches"], avg_launch_us=round(gs["avg_us"], 2),
                                       tflops=round(gs["tflops"], 1), frac=round(gs["tflops"] / PEAK_BF16_TFLOPS, 4)),
                         gemm_ms_per_step=round(gs["total_ms"], 2), gemm_flops_per_step=gs["flops"],
@@ -358,7 +423,9 @@ def main():
                                    f"+ Q-Former {cfg['qf_layers']}L + adapters + Vicuna-7B {cfg['llm_layers']}L, fwd+bwd+AdamW; "
                                    f"224x224 image, 32-token prompt, 16-token target, S={fl['S']}",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "seq_len": fl["S"],
-                       "parallelism": f"dp{world}", "trainable_params": model.store.n_params(),
+                       "parallelism": f"dp{world}", "rccl_ranks": world if world > 1 else 0,
+                       "dp_exchange": (dp.mode + ("+bf16" if dp.grad_dtype == torch.bfloat16 else "")) if world > 1 else None,
+                       "trainable_params": model.store.n_params(),
                        "peft_lora_qv_r8": bool(a.lora) and a.arch == "myriad",
                        "algorithmic_tflop_per_sample": round(fl["total"] / 1e12, 3)},
             "loss": round(float(loss), 4), "model_build_s": round(build_s, 1),

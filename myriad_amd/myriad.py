@@ -124,11 +124,16 @@ class ParamStore:
         host = torch.tensor([int(steps.get(m, 0)) for m in self.modules] or [0], dtype=torch.int32)
         self.steps_dev.copy_(host.to(self.dev))
 
-    def adamw_step(self, lr: float, weight_decay: float = 0.05, beta2: float = 0.999, grad_scale: float = 1.0):
+    def adamw_step(self, lr: float, weight_decay: float = 0.05, beta2: float = 0.999, grad_scale: float = 1.0, shard=None):
         """torch.optim.AdamW semantics (runner_base.py:132-137), fused, on the flat buffers; modules unused on every rank
-        this step are left alone (see class docstring)."""
+        this step are left alone (see class docstring).  `shard` = (lo, hi): update only that slice of the flat buffer
+        (DataParallel mode 'rs_ag': each rank owns 1/world of the optimiser state)."""
         self.step += 1
         for mi, a, b, decays in self.ranges:
+            if shard is not None:
+                a, b = max(a, shard[0]), min(b, shard[1])
+                if a >= b:
+                    continue
             ops.adamw_gated(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b], lr,
                             weight_decay if decays else 0.0, self.used[mi:mi + 1], self.steps_dev[mi:mi + 1], beta2=beta2,
                             grad_scale=grad_scale)
@@ -637,15 +642,19 @@ class MyriadHIP(nn.Module):
             loss = self._forward_impl(samples, True, vit_out=vit_out)
             self.backward()
             if dp is not None and dp.world > 1 and overlap:
-                dp.start(self.store.flat_g_comm)                  # RCCL all-reduce(sum) on the side HIP stream (grads + use flags)
+                dp.start(self.store.flat_g_comm, self.store.total)   # RCCL exchange on the side HIP stream (grads + use flags)
                 self._pending_update = (dp, lr, weight_decay)
             else:
+                shard = None
                 if dp is not None and dp.world > 1:
-                    dp.allreduce(self.store.flat_g_comm)
+                    dp.allreduce(self.store.flat_g_comm, self.store.total)
+                    shard = dp.shard(self.store.total)[:2] if dp.mode == "rs_ag" else None
                 elif allreduce is not None:
                     allreduce(self.store.flat_g_comm)
                     world = max(world, 1)
-                self.store.adamw_step(lr, weight_decay, grad_scale=1.0 / (dp.world if dp is not None else world))
+                self.store.adamw_step(lr, weight_decay, grad_scale=1.0 / (dp.world if dp is not None else world), shard=shard)
+                if shard is not None:
+                    dp.gather_params(self.store.flat_p)
         return loss
 
     def finish_update(self):
@@ -653,7 +662,10 @@ class MyriadHIP(nn.Module):
         if self._pending_update is not None:
             dp, lr, wd = self._pending_update
             dp.wait()
-            self.store.adamw_step(lr, wd, grad_scale=1.0 / dp.world)
+            shard = dp.shard(self.store.total)[:2] if getattr(dp, "mode", "allreduce") == "rs_ag" else None
+            self.store.adamw_step(lr, wd, grad_scale=1.0 / dp.world, shard=shard)
+            if shard is not None:
+                dp.gather_params(self.store.flat_p)
             self._pending_update = None
 
     @torch.no_grad()

@@ -435,6 +435,13 @@ def silu_mul_fwd_blk(gu: torch.Tensor, blk: int = SWIGLU_BLK):
     return h
 
 
+def silu_mul_bwd_blk(dh: torch.Tensor, gu: torch.Tensor, blk: int = SWIGLU_BLK):
+    M, I2 = gu.shape
+    dgu = torch.empty_like(gu)
+    _lib.check(_L().mh_silu_mul_bwd_blk(_p(dh), _p(gu), _p(dgu), M, I2 // 2, blk, _s()), "mh_silu_mul_bwd_blk")
+    return dgu
+
+
 def gemm_swiglu_fwd(x: torch.Tensor, wgu: torch.Tensor):
     """(gu [M, 2I] bf16 in the interleaved layout, act [M, I] = silu(g) * u): the gate|up projection with the gated product
     in its epilogue (separate launches, same bits, when the policy does not run the fused kernel)."""

@@ -5,9 +5,10 @@ seed rule `seed + rank` (train.py:63-72) and data-parallel gradient averaging re
 `DDP(find_unused_parameters=True)` (runners/runner_base.py:94-98).
 
 MI355X data parallelism: one process per GPU; the trainable gradients live in ONE flat fp32 buffer, so the
-exchange is a single RCCL all-reduce(sum) over xGMI issued on a side HIP stream as soon as the backward has
-produced the buffer; the fused AdamW consumes sum/world.  Unused-this-step modules contribute zeros (the buffer
-is zero-filled each backward), which is exactly DDP's find_unused_parameters semantics.
+exchange is a single RCCL all-reduce(sum) over xGMI (or a reduce-scatter / sharded-AdamW / all-gather pair, DataParallel
+mode 'rs_ag') issued on a side HIP stream as soon as the backward has produced the buffer; the fused AdamW consumes
+sum/world.  A module unused on this rank contributes zeros and a zero use flag; the flags ride the same exchange, and a
+module no rank used is skipped by the gated AdamW exactly as torch's AdamW skips a parameter whose grad is None.
 """
 from __future__ import annotations
 
@@ -64,42 +65,132 @@ def setup_seeds(seed: int, rank: int = 0) -> None:
 
 
 class DataParallel:
-    """Gradient averaging for one-process-per-GPU data parallelism over torch.distributed (backend 'nccl' is
-    RCCL on ROCm; 'gloo' in the CPU tests).  `start(flat_grad)` launches the all-reduce on a side stream
-    (overlapping whatever the main stream does next, e.g. the next step's frozen ViT forward); `wait()` makes
-    the main stream depend on it."""
+    """Gradient exchange for one-process-per-GPU data parallelism over torch.distributed (backend 'nccl' is RCCL on ROCm;
+    'gloo' in the CPU tests).  The unit of exchange is the model's flat buffer `store.flat_g_comm` = [gradients | per-module
+    use flags]; everything is issued on a side HIP stream (it overlaps whatever the main stream does next, e.g. the next
+    step's frozen ViT forward) and `wait()` makes the main stream depend on it.
 
-    def __init__(self, device=None, use_side_stream: bool = True):
+    mode (MYRIAD_DP_MODE):
+      'allreduce'  one all-reduce(sum) of the whole buffer; every rank then runs the full AdamW.
+      'rs_ag'      two phases sized for xGMI's point-to-point links (a ring all-reduce of 443 MB is per-link bound,
+                   ~5 ms; reduce-scatter + all-gather drive all 7 links at once): reduce-scatter the gradients, run AdamW on
+                   this rank's 1/world shard only (1/world of the optimiser's HBM traffic), all-gather the updated parameters.
+                   The tiny flag tail is all-reduced.  Adam moments exist only for the own shard; `gather_state` collects
+                   them for a checkpoint.
+    grad_dtype (MYRIAD_DP_GRAD_DTYPE=bf16): exchange the gradients in bf16 (half the bytes on the wire; the sum is rounded to
+      bf16 once per hop -- a numerics change the reference does not make, off by default)."""
+
+    def __init__(self, device=None, use_side_stream: bool = True, mode: Optional[str] = None, grad_dtype: Optional[str] = None):
         import torch.distributed as dist
         self.dist = dist
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.device = device
+        self.mode = mode or os.environ.get("MYRIAD_DP_MODE", "allreduce")
+        if self.mode not in ("allreduce", "rs_ag"):
+            raise ValueError(f"MYRIAD_DP_MODE={self.mode}: expected allreduce or rs_ag")
+        gd = grad_dtype or os.environ.get("MYRIAD_DP_GRAD_DTYPE", "f32")
+        self.grad_dtype = torch.bfloat16 if gd in ("bf16", "bfloat16") else torch.float32
         self.side = None
         if use_side_stream and device is not None and torch.device(device).type == "cuda" and self.world > 1:
             self.side = torch.cuda.Stream(device=device)
         self._pending = None
+        self._gloo = dist.is_initialized() and dist.get_backend() == "gloo"
 
-    def start(self, flat_grad: torch.Tensor) -> None:
-        if self.world == 1:
-            return
+    # ---- shard geometry (rs_ag): [0, total) split into `world` equal pieces of a multiple of 4 elements
+    def shard(self, total: int):
+        per = (total + self.world - 1) // self.world
+        per = (per + 3) // 4 * 4
+        lo = min(self.rank * per, total)
+        return lo, min(lo + per, total), per
+
+    def _run(self, fn):
         if self.side is not None:
             self.side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(self.side):
-                self._pending = self.dist.all_reduce(flat_grad, op=self.dist.ReduceOp.SUM, async_op=True)
+                fn()
         else:
-            self._pending = self.dist.all_reduce(flat_grad, op=self.dist.ReduceOp.SUM, async_op=True)
+            fn()
+
+    def _cast(self, t: torch.Tensor, dtype):
+        if t.dtype == dtype:
+            return t
+        if t.is_cuda:                                     # the library's cast kernels (no torch arithmetic on the data path)
+            from . import ops
+            return ops.to_bf16(t) if dtype == torch.bfloat16 else ops.to_f32(t)
+        return t.to(dtype)
+
+    def _all_reduce(self, t: torch.Tensor) -> None:
+        if self.grad_dtype != t.dtype:
+            w = self._cast(t, self.grad_dtype)
+            self.dist.all_reduce(w, op=self.dist.ReduceOp.SUM)
+            t.copy_(self._cast(w, t.dtype))
+        else:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+
+    def _reduce_scatter(self, body: torch.Tensor, per: int) -> None:
+        """Sum over ranks; rank r ends up with the sum in body[r*per:(r+1)*per] (the rest of `body` is left unspecified)."""
+        n = body.numel()
+        padded = body if n == per * self.world else torch.cat([body, body.new_zeros(per * self.world - n)])
+        w = self._cast(padded, self.grad_dtype)
+        if self._gloo:                                    # gloo has no reduce_scatter: all-reduce and keep the own piece
+            self.dist.all_reduce(w, op=self.dist.ReduceOp.SUM)
+            mine = w[self.rank * per:(self.rank + 1) * per]
+        else:
+            mine = torch.empty(per, dtype=w.dtype, device=w.device)
+            self.dist.reduce_scatter_tensor(mine, w, op=self.dist.ReduceOp.SUM)
+        lo, hi, _ = self.shard(n)
+        body[lo:hi].copy_(self._cast(mine, body.dtype)[:hi - lo])
+
+    def start(self, flat_g_comm: torch.Tensor, n_grad: Optional[int] = None) -> None:
+        """Launch the exchange of [gradients (n_grad elements) | flags].  n_grad=None: the whole buffer is gradients."""
+        if self.world == 1:
+            return
+        n_grad = flat_g_comm.numel() if n_grad is None else n_grad
+
+        def go():
+            if self.mode == "allreduce":
+                self._all_reduce(flat_g_comm)
+            else:
+                if n_grad < flat_g_comm.numel():
+                    self.dist.all_reduce(flat_g_comm[n_grad:], op=self.dist.ReduceOp.SUM)
+                self._reduce_scatter(flat_g_comm[:n_grad], self.shard(n_grad)[2])
+            ev = torch.cuda.Event() if flat_g_comm.is_cuda else None
+            if ev is not None:
+                ev.record()
+            self._pending = ev if ev is not None else True
+        self._run(go)
 
     def wait(self) -> None:
         if self._pending is not None:
-            self._pending.wait()
             if self.side is not None:
                 torch.cuda.current_stream().wait_stream(self.side)
             self._pending = None
 
-    def allreduce(self, flat_grad: torch.Tensor) -> None:
-        self.start(flat_grad)
+    def allreduce(self, flat_grad: torch.Tensor, n_grad: Optional[int] = None) -> None:
+        self.start(flat_grad, n_grad)
         self.wait()
+
+    def gather_params(self, flat_p: torch.Tensor) -> None:
+        """rs_ag: after the sharded AdamW every rank holds fresh parameters for its shard only; all-gather them in place."""
+        if self.world == 1 or self.mode != "rs_ag":
+            return
+        n = flat_p.numel()
+        lo, hi, per = self.shard(n)
+        if self._gloo or n != per * self.world:
+            mine = torch.zeros(per, dtype=flat_p.dtype, device=flat_p.device)
+            mine[:hi - lo].copy_(flat_p[lo:hi])
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(parts, mine)
+            full = torch.cat(parts)[:n]
+            flat_p.copy_(full)
+        else:
+            self.dist.all_gather_into_tensor(flat_p, flat_p[lo:hi])
+
+    def gather_state(self, store) -> None:
+        """rs_ag: collect the Adam moments of every shard (before a checkpoint is written)."""
+        self.gather_params(store.flat_m)
+        self.gather_params(store.flat_v)
 
     def barrier(self):
         if self.world > 1:

@@ -169,6 +169,64 @@ def test_module_use_flags_ride_the_gradient_allreduce_world2_gloo():
     assert torch.equal(got[0][2], got[1][2])
 
 
+def _dp_modes_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_grad, n_flags = 1003 * 4, 4                        # not a multiple of world * 4 per shard: exercises the padding
+    out = {}
+    for mode, gd in (("allreduce", "f32"), ("allreduce", "bf16"), ("rs_ag", "f32"), ("rs_ag", "bf16")):
+        torch.manual_seed(100 + rank)
+        comm = torch.cat([torch.randn(n_grad), torch.tensor([1.0, float(rank), 0.0, 1.0 - rank])])
+        mine = comm.clone()
+        dp = DataParallel(device=None, mode=mode, grad_dtype=gd)
+        dp.allreduce(comm, n_grad)
+        lo, hi, per = dp.shard(n_grad)
+        # sharded optimiser stand-in: p[shard] = -grad_sum[shard]; then every rank gathers every shard
+        p = torch.zeros(n_grad)
+        if mode == "rs_ag":
+            p[lo:hi] = -comm[lo:hi]
+            dp.gather_params(p)
+        out[(mode, gd)] = (mine.numpy().copy(), comm.numpy().copy(), (lo, hi, per), p.numpy().copy())   # by value: no shm handles
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_modes_world2_gloo():
+    """DataParallel modes behind the same train_step: fp32 / bf16 all-reduce and reduce-scatter + sharded update + all-gather
+    (the two-phase exchange sized for xGMI's point-to-point links), world 2 over gloo."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_modes_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    n_grad = 1003 * 4
+    for key in got[0]:
+        mode, gd = key
+        for r in range(2):
+            m_, c_, sh_, p_ = got[r][key]
+            got[r][key] = (torch.from_numpy(m_), torch.from_numpy(c_), sh_, torch.from_numpy(p_))
+        total = got[0][key][0] + got[1][key][0]                   # what the sum must be (fp32)
+        tol = 1e-6 if gd == "f32" else 2e-2
+        for r in range(2):
+            mine, red, (lo, hi, per), p = got[r][key]
+            assert torch.allclose(red[n_grad:], total[n_grad:], atol=tol)           # flags: summed on every rank, every mode
+            if mode == "allreduce":
+                assert torch.allclose(red[:n_grad], total[:n_grad], atol=tol * (1 + total[:n_grad].abs().max()))
+            else:
+                assert per % 4 == 0 and lo == r * per and hi == min(lo + per, n_grad)
+                assert torch.allclose(red[lo:hi], total[lo:hi], atol=tol * (1 + total.abs().max()))   # own shard reduced
+                assert torch.allclose(p, -total[:n_grad], atol=tol * (1 + total.abs().max()))          # all shards gathered
+        if mode == "rs_ag":
+            assert torch.equal(got[0][key][3], got[1][key][3])        # every rank ends with the same parameters
+
+
 def test_gemm_policy_for_the_steps_shapes():
     """mh_gemm_plan is host-only logic (no launch): which kernel / how many K splits the library picks.  Pins the
     policy for the shapes of the fine-tune step (B*S = 1184 LLaMA rows, 2056 ViT rows) and the decode token."""

@@ -299,8 +299,20 @@ def test_attention_online_softmax_spike():
 @pytest.mark.parametrize("M,I,K", [(1184, 11008, 4096), (300, 256, 128), (148, 1024, 512)])
 def test_swiglu_fused_into_the_mlp_gemms(M, I, K):
     """mh_gemm_swiglu_fwd/bwd (SiLU-gated product in the gate|up GEMM's epilogue, its backward in the down dgrad's) against
-    an fp32 torch model of LlamaMLP (modeling_llama.py:139-140) and bit-for-bit against GEMM + silu kernels."""
+    an fp32 torch model of LlamaMLP (modeling_llama.py:139-140) and bit-for-bit against GEMM + silu kernels.  The fused
+    epilogues are opt-in (MYRIAD_SWIGLU_FUSED=1: measured at parity with the separate launches); the debug hook selects them."""
+    import ctypes
+    from myriad_amd import _lib as L
+    hook = ctypes.CDLL(L.LIB_PATH).mhdbg_set_swiglu_fused
     ops.ensure_workspace(torch.device(DEV))
+    hook(1)
+    try:
+        _swiglu_case(M, I, K)
+    finally:
+        hook(0)
+
+
+def _swiglu_case(M, I, K):
     x = bf(rnd(M, K, seed=71, scale=0.5)).to(DEV)
     wg = bf(rnd(I, K, seed=72, scale=0.05)).to(DEV)
     wu = bf(rnd(I, K, seed=73, scale=0.05) + torch.arange(I)[:, None] * 1e-5).to(DEV)

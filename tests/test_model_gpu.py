@@ -288,14 +288,15 @@ class _TwoIdenticalRanks:
     """Stand-in for myriad_amd.runner.DataParallel with world 2 whose peer holds the same gradient: the async
     all-reduce(sum) returns 2*g at wait() time."""
     world = 2
+    mode = "allreduce"
 
-    def start(self, flat):
+    def start(self, flat, n_grad=None):
         self.flat = flat
 
     def wait(self):
         self.flat.mul_(2.0)
 
-    def allreduce(self, flat):
+    def allreduce(self, flat, n_grad=None):
         flat.mul_(2.0)
 
 
@@ -357,6 +358,39 @@ def test_train_step_moves_parameters_like_adamw(composite):
     assert relerr(model.store.flat_p, p_ref) < 1e-5
     loss1 = model.train_step(_samples(batch), lr=1e-3)
     assert float(loss1) < float(loss0)      # same batch, one AdamW step => loss goes down
+
+
+def test_ve_net_grads_vs_reference_bf16_forward_golden():
+    """Every conv gradient of both VE nets, first stem layers included, within 5e-2 of a committed golden made by the
+    REFERENCE's modules (networks.py:95-197) with their forward rounded to bf16 where the HIP path stores bf16
+    (tools/make_golden.py case_networks_bf16): same gates on both sides, so the cancelling sums compare tightly."""
+    from myriad_amd.myriad import ParamStore
+    from myriad_amd.networks import VENet, ve_param_specs
+    g = load("networks_bf16fwd")
+    sd = gu.adapter_weights(seed=int(g["seed"][0]))
+    gen = torch.Generator().manual_seed(int(g["seed"][1]))
+    maps = torch.rand(2, 1, 224, 224, generator=gen).to(DEV)
+    ct_i = torch.randn(2, 49, 768, generator=gen).to(DEV)
+    ct_t = torch.randn(2, 18, 4096, generator=gen).to(DEV)
+    for nm, pre, k_last, dim, ct in (("instr", "VEInstructor.", 1, 768, ct_i), ("tok", "VETokenizer.", 5, 4096, ct_t[:, 9:].contiguous())):
+        st = ParamStore(ve_param_specs(pre, dim, k_last), DEV)
+        for name, ishape, _ in st.specs:
+            st.p[name].copy_(from_reference_layout(sd[name].to(DEV), ishape))
+        net = VENet(pre, k_last, dim, st.p, st.g, DEV)
+        out = net.forward(maps)
+        want_out = g["instr_out"] if nm == "instr" else g["tok_out_sub"]
+        assert relerr(out if nm == "instr" else out[:, :, ::8], want_out) < 2e-3, nm
+        net.backward(ct)
+        for idx in (0, 3, 6, 9, 12, 15):
+            w = st.g[pre + f"meta_net.{idx}.weight"]
+            want = torch.as_tensor(g[f"{nm}_dw{idx}"])
+            if want.numel() != w.numel():
+                w = w[:: max(1, w.shape[0] // 16), :: max(1, w.shape[1] // 64)]
+            e_w = relerr(w, want)
+            e_b = relerr(st.g[pre + f"meta_net.{idx}.bias"], g[f"{nm}_db{idx}"])
+            e_n = abs(st.g[pre + f"meta_net.{idx}.weight"].norm().item() / g[f"{nm}_dw{idx}_norm"].item() - 1.0)
+            print(f"{nm} conv{idx}: dW {e_w:.3e} db {e_b:.3e} |dW| {e_n:.3e}")
+            assert e_w <= 5e-2 and e_b <= 5e-2 and e_n <= 5e-2, (nm, idx, e_w, e_b, e_n)
 
 
 def test_ve_net_grads_vs_bf16_forward_emulation():

@@ -510,6 +510,9 @@ static int big_tile_splits(int M, int N, int K, int tile_n) {
   return best;
 }
 
+// plan kernel id -> forced-variant number of dispatch()
+static inline int plan_variant(int kernel) { return kernel == 2 ? 12 : (kernel == 3 ? 3 : 0); }
+
 // The automatic policy (flags carry no variant): which kernel runs and with how many K splits.
 //   kernel 0: gemv.hip weight streaming (M <= 16: decode)
 //   kernel 2: gemm_256.hip 256x256 tile, when it can put >= 128 workgroups on the chip with >= 1024 of K each
@@ -517,6 +520,10 @@ static int big_tile_splits(int M, int N, int K, int tile_n) {
 //             profiles/r01_gemm_256.md)
 //   kernel 1: the 128x128 kernel for everything smaller -- it co-schedules two workgroups per CU and so hides its
 //             own prologue / store tail, which the one-workgroup-per-CU 256x256 kernel cannot
+//   kernel 3: the same kernel with a 128x64 tile and a 3-deep ring when even the 128x128 grid leaves most CUs without a
+//             workgroup (Q-Former / VE-net shapes: 648x768 is 36 tiles).  A lone workgroup streams its operands at one
+//             CU's L2 rate (~0.5 us per 64-deep step), so twice the workgroups is twice the CUs pulling: 14 -> 10 us at
+//             K = 768, 27 -> 19 us at K = 2304 (tools/gemm_small_sweep.py); same k order per accumulator, same bits
 static void gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits) {
   *kernel = 1;
   *splits = 1;
@@ -533,6 +540,8 @@ static void gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits) 
     const int s = auto_splits(M, N, K);
     if (s > 1 && (size_t)s * M * N * sizeof(float) <= g_ws_bytes) *splits = s;
   }
+  const long t128 = (long)((M + BM - 1) / BM) * ((N + 127) / 128);
+  if (t128 * *splits < 160) *kernel = 3;
 }
 
 extern "C" int mh_gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits) {
@@ -556,7 +565,7 @@ extern "C" int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
     if (kernel == 0)
       return mh_launch_gemv(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, (flags & MH_GEMM_OUT_F32) ? 1 : 0,
                             alpha, stream);
-    if (kernel == 2) g.flags |= 12 << MH_GEMM_VARIANT_SHIFT;
+    g.flags |= plan_variant(kernel) << MH_GEMM_VARIANT_SHIFT;
     // the split-K reduce reads `residual` and writes C element-wise, so C may alias residual (in-place accumulate)
     return splits > 1 ? run_splitk(g, splits, ws_for(stream), stream) : dispatch(g, stream);
   }
@@ -583,7 +592,7 @@ static int gemm_residual_norm(int norm, const void* A, int lda, const void* B, i
   if (splits > 1 && kernel != 0 && N <= 8192 && (ldh % 4) == 0 && (!residual || (ldr % 4) == 0) && (K % 64) == 0 &&
       (lda % 8) == 0 && (ldb % 8) == 0 && !(((uintptr_t)A | (uintptr_t)B | (uintptr_t)H) & 15)) {
     GemmArgs g = {A, lda, B, ldb, (void*)H, ldh, M, N, K, nullptr, residual, ldr, MH_GEMM_OUT_F32, 1.0f, 1, K / 64, 0L};
-    if (kernel == 2) g.flags |= 12 << MH_GEMM_VARIANT_SHIFT;
+    g.flags |= plan_variant(kernel) << MH_GEMM_VARIANT_SHIFT;
     const int nt = K / 64;                          // the split count run_splitk will settle on
     int sp = splits > nt ? nt : splits;
     const int tps = (nt + sp - 1) / sp;
@@ -635,7 +644,7 @@ extern "C" int mh_gemm_rmsnorm_bwd(const void* A, int lda, const void* B, int ld
   if (splits > 1 && kernel != 0 && (K % 64) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 &&
       !(((uintptr_t)A | (uintptr_t)B) & 15)) {
     GemmArgs g = {A, lda, B, ldb, (void*)dy_buf, N, M, N, K, nullptr, nullptr, 0, MH_GEMM_OUT_F32, 1.0f, 1, K / 64, 0L};
-    if (kernel == 2) g.flags |= 12 << MH_GEMM_VARIANT_SHIFT;
+    g.flags |= plan_variant(kernel) << MH_GEMM_VARIANT_SHIFT;
     const int nt = K / 64;                          // the split count run_splitk will settle on
     int sp = splits > nt ? nt : splits;
     const int tps = (nt + sp - 1) / sp;
@@ -671,7 +680,7 @@ extern "C" int mh_gemm_attn_rope_bwd(const void* A, int lda, const void* Bw, int
   if (splits > 1 && kernel != 0 && (K % 64) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 && (N % 8) == 0 &&
       !(((uintptr_t)A | (uintptr_t)Bw) & 15)) {
     GemmArgs g = {A, lda, Bw, ldb, do_buf, N, M, N, K, nullptr, nullptr, 0, MH_GEMM_OUT_F32, 1.0f, 1, K / 64, 0L};
-    if (kernel == 2) g.flags |= 12 << MH_GEMM_VARIANT_SHIFT;
+    g.flags |= plan_variant(kernel) << MH_GEMM_VARIANT_SHIFT;
     const int nt = K / 64;                          // the split count run_splitk will settle on
     int sp = splits > nt ? nt : splits;
     const int tps = (nt + sp - 1) / sp;

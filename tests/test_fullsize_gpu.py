@@ -109,11 +109,11 @@ def test_graph_replayed_decode_equals_eager_decode(model):
 
 def test_vit_prefetch_on_a_side_stream_changes_nothing(model):
     """train_step(next_samples=...) issues the NEXT batch's frozen ViT forward on a side stream (its own split-K scratch)
-    while this step runs: three optimisation steps over three different batches must leave bit-identical losses, parameters
-    and AdamW moments compared with the inline order."""
+    while this step runs, replayed from a hipGraph from the second batch of a shape on: four optimisation steps over four
+    different batches must leave bit-identical losses, parameters and AdamW moments compared with the inline order."""
     st = model.store
     keep = (st.flat_p.clone(), st.flat_m.clone(), st.flat_v.clone(), st.step, st.steps_dev.clone())
-    batches = [samples(2, seed=31 + i) for i in range(3)]
+    batches = [samples(2, seed=31 + i) for i in range(4)]
 
     def run(lookahead):
         st.flat_p.copy_(keep[0]); st.flat_m.copy_(keep[1]); st.flat_v.copy_(keep[2]); st.step = keep[3]; st.steps_dev.copy_(keep[4])
@@ -128,6 +128,7 @@ def test_vit_prefetch_on_a_side_stream_changes_nothing(model):
         a = run(False)
         b = run(True)
         assert model._vit_stream is not None                     # the side stream was really used
+        assert model._vit_graphs                                 # ... and the later prefetches were graph replays
         assert a[0] == b[0]
         assert torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
         assert not torch.equal(a[1], keep[0])                    # and the steps did move the parameters

@@ -246,7 +246,8 @@ def test_gemm_policy_for_the_steps_shapes():
         assert plan(2056, 6144, 1408) == (2, 1)                                          # ViT fc1
         k, s = plan(2056, 1408, 1408)                                                    # 54 tiles of 256^2: stays on 128^2
         assert k == 1 and s >= 1
-        assert plan(256, 768, 768)[0] == 1 and plan(72, 4096, 25664)[0] == 1             # Q-Former / conv-stem sizes
+        assert plan(256, 768, 768)[0] == 3 and plan(648, 768, 2304)[0] == 3              # Q-Former sizes: 128x64 tiles fill more CUs
+        assert plan(72, 4096, 25664)[0] == 1                                             # conv-stem head: 16 K splits fill the chip
         lib.mh_set_workspace(None, 0)
         assert plan(1184, 4096, 22016) == (1, 1)                                         # no workspace: nothing may split
         kernel, splits = ctypes.c_int(), ctypes.c_int()

@@ -194,12 +194,14 @@ class GemmProbe:
 def cpu_baseline(arch: str, stage: int, cfg: dict, budget_note: str = "") -> dict:
     """Reference-equivalent CPU path (the oracle, pinned to the reference's modules by tests/golden) timed on the
     host cores on a bounded sample: full width, reduced depth, B=1; per-component times are scaled linearly to the
-    full depth (ViT 39 blocks fwd; Q-Former 12 layers, LLaMA 32 layers, VE nets fwd+bwd)."""
+    full depth (ViT 39 blocks fwd; Q-Former 12 layers, LLaMA 32 layers, VE nets fwd+bwd).  The sample is run at several
+    thread counts and the fastest is reported (`cores` = the threads that run used): at S = 148 rows the host BLAS is
+    slower on 128 threads than on 16."""
     from oracle import myriad_ref as R
     from tests import golden_utils as gu
     torch.manual_seed(0)
-    nth = torch.get_num_threads()
-    kv, kq, kl = 8, 6, 8          # ~10 s of host work on 128 threads; deeper samples only move the extrapolation by percents
+    nth0 = torch.get_num_threads()
+    kv, kq, kl = 8, 6, 8          # a few seconds of host work per thread count; deeper samples only move the extrapolation by percents
     V = 2048
     sd = {}
     sd.update(gu.vit_weights(cfg["vit_dim"], kv, cfg["vit_heads"], cfg["vit_hidden"], cfg["patch"], 257, seed=1))
@@ -211,6 +213,28 @@ def cpu_baseline(arch: str, stage: int, cfg: dict, budget_note: str = "") -> dic
     for k in train:
         sd[k] = sd[k].clone().requires_grad_(True)
     image, maps, before, after, tgt, tmask = gu.synthetic_batch(1, V, seed=6)
+    best, scan = None, {}
+    for nth in sorted({t for t in (8, 16, 32, 64, nth0) if t <= max(nth0, 8)}):
+        torch.set_num_threads(nth)
+        for k in train:
+            sd[k].grad = None
+        one = _cpu_baseline_once(R, sd, train, (image, maps, before, after, tgt, tmask), arch, stage, cfg, (kv, kq, kl))
+        scan[str(nth)] = round(1.0 / one[0], 4)
+        if best is None or one[0] < best[0]:
+            best = one + (nth,)
+    torch.set_num_threads(nth0)
+    total, measured, nth = best
+    return dict(value=1.0 / total, unit="images/s", cores=nth, kind="port", images_per_s_by_threads=scan,
+                sample=f"oracle (CPU restatement pinned to the reference modules) fp32 B=1 {arch} stage {stage}: "
+                       f"ViT {kv}/{cfg['vit_depth']} blocks, Q-Former {kq}/{cfg['qf_layers']}, LLaMA {kl}/"
+                       f"{cfg['llm_layers']} layers timed fwd+bwd and scaled linearly to full depth, AdamW on a 16 M-element slice "
+                       f"scaled to the trainable count ({measured:.1f} s measured, {total:.1f} s/step extrapolated at the fastest "
+                       f"of {sorted(int(k) for k in scan)} threads; host has {os.cpu_count()} logical cores)")
+
+
+def _cpu_baseline_once(R, sd, train, batch, arch, stage, cfg, depths):
+    kv, kq, kl = depths
+    image, maps, before, after, tgt, tmask = batch
     t = {}
 
     def clock(name, fn):
@@ -252,11 +276,7 @@ def cpu_baseline(arch: str, stage: int, cfg: dict, budget_note: str = "") -> dic
     t_adam = (time.perf_counter() - t0) * n_train / ns
     t["adamw_scaled"] = t_adam
     total += t_adam
-    return dict(value=1.0 / total, unit="images/s", cores=nth, kind="port",
-                sample=f"oracle (CPU restatement pinned to the reference modules) fp32 B=1 {arch} stage {stage}: "
-                       f"ViT {kv}/{cfg['vit_depth']} blocks, Q-Former {kq}/{cfg['qf_layers']}, LLaMA {kl}/"
-                       f"{cfg['llm_layers']} layers timed fwd+bwd and scaled linearly to full depth "
-                       f"({sum(t.values()):.1f} s measured, {total:.1f} s/step extrapolated)")
+    return total, sum(t.values())
 
 
 def main():

@@ -636,7 +636,8 @@ class MyriadHIP(nn.Module):
         static_in = torch.empty_like(image).contiguous()
         static_in.copy_(image)
         g = torch.cuda.CUDAGraph()
-        with torch.no_grad(), torch.cuda.graph(g, stream=self._vit_stream):
+        # thread_local: a data-parallel run has RCCL's watchdog thread polling events while this thread captures
+        with torch.no_grad(), torch.cuda.graph(g, stream=self._vit_stream, capture_error_mode="thread_local"):
             static_out = self.visual_encoder.forward(static_in)
         self._vit_graphs[tuple(image.shape)] = (g, static_in, static_out)
         return self._vit_graphs[tuple(image.shape)]

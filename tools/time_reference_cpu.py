@@ -108,8 +108,8 @@ def main():
             del lm, opt
         (r2, S), (r4, _) = res[(arch, KS[0])], res[(arch, KS[1])]
         per_layer = ((r4["fwd"] + r4["bwd"]) - (r2["fwd"] + r2["bwd"])) / (KS[1] - KS[0])     # LLaMA layers only differ in fwd / bwd
-        vit = min(r2["vit"], r4["vit"]) * 39.0 / a.vit_depth
-        full = vit + r2["fwd"] + r2["bwd"] + per_layer * (32 - KS[0]) + min(r2["opt"], r4["opt"])
+        vit_s = min(r2["vit"], r4["vit"]) * 39.0 / a.vit_depth
+        full = vit_s + r2["fwd"] + r2["bwd"] + per_layer * (32 - KS[0]) + min(r2["opt"], r4["opt"])
         print(f"| {arch} stage {stage} | {S} | **32 (extrapolated: {per_layer:.2f} s per layer)** | | | | | **{full:.1f} s/step = {1.0 / full:.4f} images/s** |", flush=True)
     print("\nLoRA on q/v (peft, un-vendored and absent here) is not part of this timing; it adds 2 x 32 rank-8 products to a step "
           "that is dominated by the frozen 7B matmuls.")

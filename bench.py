@@ -383,8 +383,19 @@ def main():
             if os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 if dom.split(":")[0] in tj.get("kernel", ""):
-                    traffic = dict(bytes_per_launch=round(tj["traffic_bytes_per_launch"]), read=round(tj["read_bytes_per_launch"]),
-                                   write=round(tj["write_bytes_per_launch"]),
+                    rd, wr_, src_n = tj["read_bytes_per_launch"], tj["write_bytes_per_launch"], 0
+                    if tj.get("by_workgroups"):
+                        # average over exactly the launches timed here (the ViT's launches run inside a graph, outside the probe)
+                        rd = wr_ = 0.0
+                        for (m_, n_, k_), cnt, _, _ in pr.shapes:
+                            kid, sp = pr.ops.gemm_plan(m_, n_, k_)
+                            ent = tj["by_workgroups"].get(str(((m_ + 255) // 256) * ((n_ + 255) // 256)))
+                            if kid == 2 and sp == 1 and (m_, n_, k_) not in pr.fused and ent:
+                                rd += cnt * ent["read_bytes_per_launch"]
+                                wr_ += cnt * ent["write_bytes_per_launch"]
+                                src_n += cnt
+                        rd, wr_ = (rd / src_n, wr_ / src_n) if src_n else (tj["read_bytes_per_launch"], tj["write_bytes_per_launch"])
+                    traffic = dict(bytes_per_launch=round(rd + wr_), read=round(rd), write=round(wr_),
                                    algorithmic_bytes_per_launch=round(dk["algorithmic_mb_per_launch"] * 1e6),
                                    source=f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)")
             # the same kernel over ALL its launches of the step: split-K launches are timed as a pair (partial-product kernel +

@@ -50,6 +50,33 @@ def test_vision_expert_vs_reference_golden(name):
         assert (a - b).abs().max() < 1e-2
 
 
+def test_vision_expert_full_depth_vs_oracle():
+    """The full ImageBind-Huge vision trunk (32 blocks x 1280, taps after blocks 8/16/24/32 as adrefexpert_v2.py:16-29 taps
+    them) and both map heads against the oracle (pinned to the reference classes at reduced depth by the goldens above) on
+    the same seeded weights: the depth the goldens cannot afford."""
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    D, heads, blocks, C, B, k, seed = 1280, 16, 32, 1024, 2, 1, 4242
+    layers = [7, 15, 23, 31]
+    sd = gu.expert_weights(D, blocks, C, len(layers), seed)
+    images, refs, text = gu.expert_inputs(B, k, C, seed + 100)
+    emb_o, taps_o = X.vision_trunk(sd, images, heads, layers, blocks)
+    _, rtaps_o = X.vision_trunk(sd, refs, heads, layers, blocks)
+    dec = {kk[len("image_decoder."):]: v for kk, v in sd.items() if kk.startswith("image_decoder.")}
+    zmap_o, zmask_o = X.zero_shot_maps(taps_o, dec, text)
+    omap_o, omask_o = X.one_shot_maps(taps_o, rtaps_o)
+    ex = VisionExpertHIP(sd, heads, layers, DEV)
+    emb, taps = ex.trunk.forward(images.to(DEV), want_embedding=True)
+    errs = [relerr(t, to) for t, to in zip(taps, taps_o)]
+    print("tap errors", errs, "embedding", (emb.cpu() - emb_o).abs().max().item())
+    for i, e in enumerate(errs):
+        assert e < 2e-2, (i, e)                                   # activations: 2e-2 of max-abs (measured 5e-3 at full depth)
+    assert (emb.cpu() - emb_o).abs().max() < 2e-2                # unit vectors
+    (zmap, zmask), (omap, omask) = ex.forward(images, text, refs)
+    assert (zmap.cpu() - zmap_o).abs().max() < 1e-1 and (zmap.cpu() - zmap_o).abs().mean() < 1e-2
+    assert (zmask.cpu() - zmask_o).abs().max() < 1e-1
+    assert (omap.cpu() - omap_o).abs().max() < 2e-2 and (omask.cpu() - omask_o).abs().max() < 2e-2
+
+
 def test_map_head_kernels_vs_torch():
     """The fp32 head kernels on their own against torch (tight tolerances: no bf16 involved)."""
     g = torch.Generator().manual_seed(5)

@@ -6,12 +6,16 @@ with --json PATH, the dominant GEMM kernel's per-launch traffic for bench.py's r
 import collections, csv, glob, json, re, sys
 
 d = sys.argv[1]
+by_grid = {}                                     # counter -> {workgroups of an unsplit gemm_256 launch: [launches, sum]}
+
+
 def load(counter):
     agg = collections.defaultdict(lambda: [0, 0.0])
-    gy_of = {}                                   # Dispatch_Id -> grid y (K splits), from the kernel trace of the same pass
+    gy_of, gx_of = {}, {}                        # Dispatch_Id -> grid y (K splits) / workgroups in x, from the kernel trace of the same pass
     for f in glob.glob(f"{d}/{counter}/**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             gy_of[r["Dispatch_Id"]] = int(r["Grid_Size_Y"]) // max(1, int(r["Workgroup_Size_Y"]))
+            gx_of[r["Dispatch_Id"]] = int(r["Grid_Size_X"]) // max(1, int(r["Workgroup_Size_X"]))
     for f in glob.glob(f"{d}/{counter}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
@@ -21,6 +25,10 @@ def load(counter):
             key = (name, gy if "gemm" in name else 0)
             agg[key][0] += 1
             agg[key][1] += float(r["Counter_Value"])
+            if "gemm_256" in name and gy == 1:
+                e = by_grid.setdefault(counter, {}).setdefault(gx_of.get(r["Dispatch_Id"], 0), [0, 0.0])
+                e[0] += 1
+                e[1] += float(r["Counter_Value"])
     return agg
 fe, wr = load("FETCH_SIZE"), load("WRITE_SIZE")
 rows = []
@@ -39,7 +47,12 @@ if "--json" in sys.argv:
     dom = [r for r in rows if "gemm_256" in r[0][0] and r[0][1] == 1]
     if dom:
         (name, gy), n, rd, wb = dom[0]
+        grids = {}
+        for gx, (cnt, tot) in by_grid.get("FETCH_SIZE", {}).items():
+            wcnt, wtot = by_grid.get("WRITE_SIZE", {}).get(gx, [1, 0.0])
+            grids[str(gx)] = {"launches": cnt, "read_bytes_per_launch": 2.0 * tot * 1024 / cnt,
+                              "write_bytes_per_launch": wtot * 1024 / max(1, wcnt)}
         json.dump({"kernel": name, "launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wb,
-                   "traffic_bytes_per_launch": rd + wb,
+                   "traffic_bytes_per_launch": rd + wb, "by_workgroups": grids,
                    "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only); read = 2 x FETCH_SIZE KiB (gfx950), write = WRITE_SIZE KiB; unsplit gemm_256_kernel launches of python bench.py --steps 2 --warmup 1"},
                   open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)

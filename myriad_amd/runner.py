@@ -185,7 +185,7 @@ class DataParallel:
             full = torch.cat(parts)[:n]
             flat_p.copy_(full)
         else:
-            self.dist.all_gather_into_tensor(flat_p, flat_p[lo:hi])
+            self.dist.all_gather_into_tensor(flat_p, flat_p[lo:hi].clone())   # a copy: input and output may not alias
 
     def gather_state(self, store) -> None:
         """rs_ag: collect the Adam moments of every shard (before a checkpoint is written)."""

@@ -336,6 +336,8 @@ def main():
         return model.train_step(smp, sched.step(0, i), 0.05, dp=dp if world > 1 else None, world=world, overlap=overlap,
                                 next_samples=smp if prefetch else None)
 
+    if prefetch:
+        model.prepare_vit_graph(samples)      # the look-ahead's hipGraph is captured here, not inside a timed step (any --warmup)
     for i in range(a.warmup):
         step(i)
     model.finish_update()
@@ -425,6 +427,8 @@ def main():
     if not a.no_b1 and rank == 0 and world == 1:
         try:
             s1 = make_samples(1, cfg["vocab"], 42, dev)
+            if prefetch:
+                model.prepare_vit_graph(s1)
             for i in range(2):
                 step(i, s1)
             torch.cuda.synchronize()

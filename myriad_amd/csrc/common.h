@@ -38,17 +38,36 @@ __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
 // element index), so backward regenerates it instead of storing it.  32-bit arithmetic only (murmur3 finaliser over a
 // seed/index mix): the first version used a 64-bit splitmix and its multi-word multiplies made the LoRA kernels
 // ALU-bound.  Returns 1/(1-p) for kept elements, 0 for dropped ones; u is a 24-bit uniform in [0,1).
-__device__ __forceinline__ float dropout_keep(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
-  if (p <= 0.f) return 1.f;
+__device__ __forceinline__ unsigned dropout_hash(unsigned long long seed, unsigned long long idx) {
   unsigned h = (unsigned)idx * 0x9E3779B1u + ((unsigned)seed ^ ((unsigned)(idx >> 32) * 0x85EBCA77u));
-  h ^= (unsigned)(seed >> 32);
+  h ^= (unsigned)(seed >> 32) & 0x7FFFFFFFu;
   h ^= h >> 16;
   h *= 0x85EBCA6Bu;
   h ^= h >> 13;
   h *= 0xC2B2AE35u;
   h ^= h >> 16;
+  return h;
+}
+// second, independent draw derived from the first hash (one more multiply-xorshift round instead of a second full hash)
+__device__ __forceinline__ unsigned dropout_hash2(unsigned h) {
+  h = (h ^ 0x68E31DA4u) * 0x2C1B3C6Du;
+  return h ^ (h >> 15);
+}
+// Bit 63 of the seed selects the second draw of the same (seed, index): two masks for the price of ~one hash
+// (dropout_keep_pair), e.g. peft's separate nn.Dropout on q_proj and v_proj.
+__device__ __forceinline__ float dropout_keep(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+  if (p <= 0.f) return 1.f;
+  unsigned h = dropout_hash(seed, idx);
+  if (seed >> 63) h = dropout_hash2(h);
   const float u = (float)(h >> 8) * (1.0f / 16777216.0f);
   return u >= p ? inv_keep : 0.f;
+}
+__device__ __forceinline__ void dropout_keep_pair(unsigned long long seed, unsigned long long idx, float p, float inv_keep,
+                                                  float& k0, float& k1) {
+  if (p <= 0.f) { k0 = k1 = 1.f; return; }
+  const unsigned h = dropout_hash(seed, idx);
+  k0 = (float)(h >> 8) * (1.0f / 16777216.0f) >= p ? inv_keep : 0.f;
+  k1 = (float)(dropout_hash2(h) >> 8) * (1.0f / 16777216.0f) >= p ? inv_keep : 0.f;
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -8,6 +8,8 @@
 //               (thread-per-column partial sums over row chunks + fixed-order reduce: deterministic)
 //   lora_refresh_border: writes bf16(B_q), bf16(B_v) into the borders of W_ext and W_ext^T.
 // keep(m,d) = hash(seed, m*D+d) >= p ? 1/(1-p) : 0  -- regenerated, never stored.  R2 = 2r (q then v), r in {8,16}.
+// peft gives q_proj and v_proj their own nn.Dropout, i.e. independent masks: rows j < r of A (q) see keep(seed, .), rows
+// j >= r (v) see the second draw of the same hash (seed with bit 63 set; common.h dropout_keep_pair).
 #include "common.h"
 
 #define LR_NT 256
@@ -33,9 +35,10 @@ __global__ __launch_bounds__(LD_NW * 64) void lora_down_kernel(const bf16_t* __r
   int mrow = m0 + lr;
   mrow = mrow < M ? mrow : M - 1;
   const float ik = 1.f / (1.f - p);
-  float4_t acc[NJ];
+  constexpr int r = R2 / 2;
+  float4_t acc[NJ], accv[NJ];                      // acc: x under the q mask, accv: x under the v mask
 #pragma unroll
-  for (int jj = 0; jj < NJ; ++jj) acc[jj] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  for (int jj = 0; jj < NJ; ++jj) { acc[jj] = (float4_t){0.f, 0.f, 0.f, 0.f}; accv[jj] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
   const int steps = D / 32;
   const int per = (steps + LD_NW - 1) / LD_NW;
   const int s0 = wave * per, s1 = (s0 + per) < steps ? (s0 + per) : steps;
@@ -59,23 +62,30 @@ __global__ __launch_bounds__(LD_NW * 64) void lora_down_kernel(const bf16_t* __r
     for (int u = 0; u < UN; ++u) {
       if (st + u >= s1) xv[u] = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
       const int k = (st + u) * 32 + lg * 8;
+      short8_t xq = xv[u], xw = xv[u];
       if (p > 0.f) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e)
-          if (dropout_keep(seed, (unsigned long long)((long)mrow * D + k + e), p, ik) == 0.f) xv[u][e] = 0;
+        for (int e = 0; e < 8; ++e) {
+          float kq, kv;
+          dropout_keep_pair(seed, (unsigned long long)((long)mrow * D + k + e), p, ik, kq, kv);
+          if (kq == 0.f) xq[e] = 0;
+          if (kv == 0.f) xw[e] = 0;
+        }
       }
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) {
         const short8_t av = {(short)f2bf(a0[u][jj][0]), (short)f2bf(a0[u][jj][1]), (short)f2bf(a0[u][jj][2]), (short)f2bf(a0[u][jj][3]),
                              (short)f2bf(a1[u][jj][0]), (short)f2bf(a1[u][jj][1]), (short)f2bf(a1[u][jj][2]), (short)f2bf(a1[u][jj][3])};
-        acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xv[u], av, acc[jj], 0, 0, 0);   // D[m = 4*lg + r][j = lr]
+        // D[m = 4*lg + r][j = lr]; a 16-row block of A that is all q (or all v) needs only its own product
+        if (jj * 16 < r) acc[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xq, av, acc[jj], 0, 0, 0);
+        if (jj * 16 + 16 > r) accv[jj] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xw, av, accv[jj], 0, 0, 0);
       }
     }
   }
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) red[wave][jj][(4 * lg + r) * 16 + lr] = acc[jj][r];
+    for (int q = 0; q < 4; ++q) red[wave][jj][(4 * lg + q) * 16 + lr] = (jj * 16 + lr < r) ? acc[jj][q] : accv[jj][q];
   __syncthreads();
   const float scale = p > 0.f ? s * ik : s;
   for (int i = threadIdx.x; i < NJ * 256; i += LD_NW * 64) {
@@ -104,17 +114,25 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(const float* __restrict__ 
   const int m1 = (m0 + rows_per) < M ? (m0 + rows_per) : M;
   for (int m = m0; m < m1; ++m) {
     const float* row = dx_ext + (long)m * ld;
-    float4_t acc = (float4_t){0.f, 0.f, 0.f, 0.f};
+    float4_t acc = (float4_t){0.f, 0.f, 0.f, 0.f}, accv = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < R2; ++j) {
+    for (int j = 0; j < R2 / 2; ++j) {
       const float g = row[D + j];
       acc[0] += g * a[j][0]; acc[1] += g * a[j][1]; acc[2] += g * a[j][2]; acc[3] += g * a[j][3];
+    }
+#pragma unroll
+    for (int j = R2 / 2; j < R2; ++j) {
+      const float g = row[D + j];
+      accv[0] += g * a[j][0]; accv[1] += g * a[j][1]; accv[2] += g * a[j][2]; accv[3] += g * a[j][3];
     }
     const float4_t base = *reinterpret_cast<const float4_t*>(row + d);
     float4_t o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e)
-      o[e] = base[e] + s * acc[e] * dropout_keep(seed, (unsigned long long)((long)m * D + d + e), p, ik);
+    for (int e = 0; e < 4; ++e) {
+      float kq, kv;
+      dropout_keep_pair(seed, (unsigned long long)((long)m * D + d + e), p, ik, kq, kv);
+      o[e] = base[e] + s * (acc[e] * kq + accv[e] * kv);
+    }
     *reinterpret_cast<float4_t*>(out + (long)m * D + d) = o;
   }
 }
@@ -173,10 +191,13 @@ __global__ __launch_bounds__(LR_WG_NT) void lora_wgrad_partial_kernel(
       if (live) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float xd = bf2f((bf16_t)xv[u][e]) * dropout_keep(seed, (unsigned long long)((long)m * D + d + e), p, ik);
+          float kq, kv;
+          dropout_keep_pair(seed, (unsigned long long)((long)m * D + d + e), p, ik, kq, kv);
+          const float x0 = bf2f((bf16_t)xv[u][e]);
+          const float xd = x0 * kq, xw = x0 * kv;
           const float gq = bf2f((bf16_t)qv[u][e]), gv = bf2f((bf16_t)vv[u][e]);
 #pragma unroll
-          for (int j = 0; j < R2; ++j) a[j][e] += sg[j] * xd;
+          for (int j = 0; j < r; ++j) { a[j][e] += sg[j] * xd; a[r + j][e] += sg[r + j] * xw; }
 #pragma unroll
           for (int j = 0; j < r; ++j) {
             bq[j][e] += gq * st[j];

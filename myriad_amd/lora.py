@@ -10,7 +10,8 @@ MI355X formulation -- the rank-r UP projection rides the main MFMA GEMMs as a K-
 
 so q/k/v are rounded to bf16 once and no extra pass over the [B*S, 12288] qkv buffer is needed; the skinny parts
 (lora-down, dx correction, dA/dB) are wavefront-primitive kernels in csrc/lora.hip that regenerate the dropout mask
-from (seed, index) instead of storing it.  The 64-column border holds s*t_q (r) | s*t_v (r) | zeros.
+from (seed, index) instead of storing it -- one mask per wrapped Linear (peft gives q_proj and v_proj their own nn.Dropout).
+The 64-column border holds s*t_q (r) | s*t_v (r) | zeros.
 """
 from __future__ import annotations
 
@@ -23,6 +24,7 @@ from . import _lib, ops
 
 BF16, F32 = torch.bfloat16, torch.float32
 BORDER = 64
+V_TAG = 1 << 63      # v_proj's dropout mask is the second draw of q_proj's hash: seed | bit 63 (csrc/common.h dropout_keep_pair); seeds are 63-bit
 PEFT_PREFIX = "llama_model.base_model.model.model.layers."
 
 

@@ -628,6 +628,21 @@ class MyriadHIP(nn.Module):
             ev.record()
         self._vit_prefetched = (samples, out, ev)
 
+    def prepare_vit_graph(self, samples) -> None:
+        """Capture the look-ahead graph for this batch's image shape now (one eager pass + the capture: ~0.1 s), so that no
+        later train_step pays for it.  Without this call the capture happens at the second look-ahead of a shape."""
+        image = self._image_of(samples)
+        key = tuple(image.shape)
+        if not self._vit_graph_on or key in self._vit_graphs or image.dtype != F32:
+            return
+        if self._vit_stream is None:
+            self._vit_stream = self._side_stream("vit")
+        self._vit_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._vit_stream), torch.no_grad():
+            self.visual_encoder.forward(image)            # first-call set-up of every kernel happens outside the capture
+        self._vit_seen[key] = max(1, self._vit_seen.get(key, 0))
+        self._capture_vit(image)
+
     def _capture_vit(self, image):
         """Capture visual_encoder.forward at this input shape into a hipGraph on the ViT side stream (whose split-K scratch the
         captured launches keep using on replay).  Called after one eager pass at the shape, so no kernel does first-call set-up

@@ -231,7 +231,8 @@ def llama_layer(sd: SD, p: str, x: Tensor, mask: Tensor, position_ids: Tensor, h
 
     `lora` (row a-14, PARITY UNPINNED -- peft is un-vendored): dict(r, alpha, dropout_mask)
     applies peft's published LoRA form y = W x + (alpha/r) * B(A(drop(x))) on q_proj and
-    v_proj (target_modules at myriad.py:171-178)."""
+    v_proj (target_modules at myriad.py:171-178).  Each wrapped Linear owns its nn.Dropout, so
+    `dropout_mask` is a dict {"q_proj": keep/(1-p) factors, "v_proj": ...} (or one tensor for both)."""
     B, S, D = x.shape
     d = D // heads
     h = rms_norm(x, sd[p + "input_layernorm.weight"], eps)
@@ -241,8 +242,9 @@ def llama_layer(sd: SD, p: str, x: Tensor, mask: Tensor, position_ids: Tensor, h
         ka = p + f"self_attn.{name}.lora_A.default.weight"
         if lora is not None and ka in sd:
             xin = inp
-            if lora.get("dropout_mask") is not None:
-                xin = inp * lora["dropout_mask"]
+            dm = lora.get("dropout_mask")
+            if dm is not None:
+                xin = inp * (dm[name] if isinstance(dm, dict) else dm)
             y = y + (lora["alpha"] / lora["r"]) * F.linear(
                 F.linear(xin, sd[ka]), sd[p + f"self_attn.{name}.lora_B.default.weight"])
         return y

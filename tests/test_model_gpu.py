@@ -435,7 +435,8 @@ def test_ve_net_grads_vs_bf16_forward_emulation():
 @pytest.mark.parametrize("dropout", [0.0, 0.05])
 def test_llama_lora_qv_vs_oracle(dropout):
     """q/v LoRA as a K-border of the qkv GEMM vs the oracle's restated peft formula (parity unpinned by the
-    reference: peft is un-vendored).  With dropout the oracle is fed the HIP path's own keep-mask."""
+    reference: peft is un-vendored).  With dropout the oracle is fed the HIP path's own keep-masks (one per wrapped
+    Linear, as peft's per-module nn.Dropout draws them: the v mask is the q mask's hash under lora.V_TAG)."""
     from myriad_amd.lora import LoraQV, PEFT_PREFIX, lora_param_specs
     from myriad_amd.myriad import ParamStore
     D, layers, heads, inter, V, r = 4096, 1, 32, 11008, 1000, 8
@@ -467,8 +468,12 @@ def test_llama_lora_qv_vs_oracle(dropout):
     if dropout > 0:
         seed = (3 * 1315423911 + 0 * 2654435761 + 12345) & 0x7FFFFFFFFFFFFFFF
         ones = torch.ones(48, D, dtype=torch.bfloat16, device=DEV)
-        dmask = ops.dropout_bf16(ones, dropout, seed).float().cpu().view(2, 24, D)     # keep/(1-p) factors
-        assert 0.90 < float((dmask > 0).float().mean()) < 0.99
+        from myriad_amd.lora import V_TAG
+        dmask = {"q_proj": ops.dropout_bf16(ones, dropout, seed).float().cpu().view(2, 24, D),      # keep/(1-p) factors
+                 "v_proj": ops.dropout_bf16(ones, dropout, seed ^ V_TAG).float().cpu().view(2, 24, D)}
+        assert 0.90 < float((dmask["q_proj"] > 0).float().mean()) < 0.99
+        both = float(((dmask["q_proj"] > 0) & (dmask["v_proj"] > 0)).float().mean())
+        assert abs(both - (1 - dropout) ** 2) < 5e-3                # independent draws, not one shared mask
     e = emb.clone().requires_grad_(True)
     loss_ref, _ = R.llama_causal_lm(osd, e, mask, labels, heads, lora=dict(r=r, alpha=16.0, dropout_mask=dmask))
     loss_ref.backward()

@@ -1,0 +1,2 @@
+timeout 1200 python -m pytest tests/test_model_gpu.py tests/test_kernels_gpu.py -x -q 2>&1 | tail -4
+python bench.py --steps 10 --warmup 1 --no-cpu-baseline --no-probe 2>&1 | tail -1 | cut -c1-200

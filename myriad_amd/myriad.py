@@ -293,12 +293,14 @@ class MyriadHIP(nn.Module):
     def state_dict(self, *a, **k):
         """Trainable parameters under the reference's key names and tensor layouts (runner_base.py:598-605 keeps
         exactly the requires_grad parameters)."""
+        self.finish_update()
         out = OrderedDict()
         for name, _, rshape in self.store.specs:
             out[name] = to_reference_layout(self.store.p[name].detach(), rshape).cpu()
         return out
 
     def load_state_dict(self, sd, strict: bool = False):
+        self.finish_update()                              # a delayed update must not land on top of the loaded values
         missing = []
         for name, ishape, _ in self.store.specs:
             if name in sd:
@@ -499,6 +501,7 @@ class MyriadHIP(nn.Module):
     def forward(self, samples):
         """`Myriad.forward` (myriad.py:377-431).  Returns {"loss": 0-d tensor}; `loss.backward()` works."""
         need_grad = torch.is_grad_enabled() and self.training and self.store.total > 0
+        self.finish_update()                              # a delayed update of train_step() lands before parameters are read
         with torch.no_grad():
             loss = self._forward_impl(samples, need_grad)
         if need_grad:
@@ -704,15 +707,18 @@ class MyriadHIP(nn.Module):
         return loss
 
     def finish_update(self):
-        """Apply a delayed optimiser update (overlap mode): wait for the gradient all-reduce, then fused AdamW."""
+        """Apply a delayed optimiser update (overlap mode): wait for the gradient exchange, if any, then fused AdamW."""
         if self._pending_update is not None:
             dp, lr, wd = self._pending_update
+            self._pending_update = None
+            if dp is None:
+                self.store.adamw_step(lr, wd)
+                return
             dp.wait()
             shard = dp.shard(self.store.total)[:2] if getattr(dp, "mode", "allreduce") == "rs_ag" else None
             self.store.adamw_step(lr, wd, grad_scale=1.0 / dp.world, shard=shard)
             if shard is not None:
                 dp.gather_params(self.store.flat_p)
-            self._pending_update = None
 
     @torch.no_grad()
     def generate(self, samples, **generate_kwargs):
@@ -722,6 +728,7 @@ class MyriadHIP(nn.Module):
         to batch row 0), do_sample + top_p + temperature (see LlamaHIP.greedy_generate: arg-max whenever p_max >= top_p,
         a host-side draw otherwise), min_length, use_cache.  Anything that would change the decoding rule and is not
         implemented raises instead of being ignored."""
+        self.finish_update()
         kw = dict(generate_kwargs)
         stops = kw.pop("stop_ids", None)
         crit = kw.pop("stopping_criteria", None)

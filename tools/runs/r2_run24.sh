@@ -1,0 +1,6 @@
+timeout 900 python -m pytest tests/test_fullsize_gpu.py tests/test_entrypoints_gpu.py -x -q 2>&1 | tail -3
+python tools/step_phases.py --batch 8 2>&1 | tail -13
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-probe 2>&1 | tail -1 | cut -c1-200
+MYRIAD_NO_OVERLAP=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-probe 2>&1 | tail -1 | cut -c1-200
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-probe 2>&1 | tail -1 | cut -c1-200
+MYRIAD_NO_OVERLAP=1 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-probe 2>&1 | tail -1 | cut -c1-200

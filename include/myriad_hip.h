@@ -151,6 +151,12 @@ int mh_lora_down(const void* x, long ldx, const float* A, void* border, long ldo
                  unsigned long long seed, mh_stream_t st);
 int mh_lora_dx(const float* dx_ext, long ld, const float* A, float* out, int M, int D, int R2, float s, float p,
                unsigned long long seed, mh_stream_t st);
+/* The qkv dgrad with the LoRA border, [M, D+64] = dqkv . [W_qkv | B_ext]^T-layout operand (myriad.py:170-180 under autograd),
+ * and the LoRA dx correction that reads it, in one call: when mh_gemm_plan(M, D+64, K) splits K the correction kernel sums the
+ * fp32 partial slabs itself (no reduce launch, same bits) and writes the summed border d(s*t) [M, 64] to border_out; otherwise
+ * the product goes through dx_ext_buf [M, D+64] (which then holds the border) and border_out is left alone. */
+int mh_gemm_lora_dx(const void* A, int lda, const void* Bw, int ldb, float* dx_ext_buf, const float* loraA, float* dxn,
+                    float* border_out, int M, int D, int K, int R2, float s, float p, unsigned long long seed, mh_stream_t stream);
 long mh_lora_wgrad_ws_floats(int D, int R2);
 int mh_lora_wgrad(const void* x, long ldx, const float* dx_ext, long ldg, const void* dq, const void* dv, long ldq,
                   const void* border, long ldb, float* dA, float* dBq, float* dBv, float* ws, int M, int D, int R2,

@@ -659,6 +659,41 @@ extern "C" int mh_gemm_rmsnorm_bwd(const void* A, int lda, const void* B, int ld
   return mh_launch_rmsnorm_bwd(dy_buf, 1, 0, N, x, w, dres, dx, dx_bf16, M, N, eps, stream);
 }
 
+int mh_launch_lora_dx(const float* dx_ext, long ld, int nslab, long slab, const float* A, float* out, float* border_out, int M,
+                      int D, int R2_, float s, float p, unsigned long long seed, hipStream_t stream);
+
+// The qkv dgrad with the LoRA border, [M, D + 64] = dqkv . [W_qkv | B_ext] (myriad_amd/lora.py), followed by the LoRA dx
+// correction that reads it (lora.hip).  When the policy splits K the correction kernel sums the partial slabs itself (same
+// order as splitk_reduce_kernel, so the same bits as mh_gemm_bf16_nt + mh_lora_dx) and writes the summed border [M, 64] for the
+// weight-gradient kernel (border_out [M, 64] f32); otherwise (mh_gemm_plan(M, D + 64, K) reports one split) the product goes
+// through dx_ext_buf [M, D + 64] f32, which then also holds the border, and border_out is not written.  dxn [M, D] f32.
+extern "C" int mh_gemm_lora_dx(const void* A, int lda, const void* Bw, int ldb, float* dx_ext_buf, const float* loraA, float* dxn,
+                               float* border_out, int M, int D, int K, int R2, float s, float p, unsigned long long seed,
+                               hipStream_t stream) {
+  if (M <= 0) return MH_OK;
+  const int N = D + 64;
+  if (!loraA || !dxn || D <= 0 || (D % 4) != 0) return MH_ERR_ARG;
+  int kernel = 1, splits = 1;
+  if (K > 0) gemm_plan(M, N, K, MH_GEMM_OUT_F32, &kernel, &splits);
+  if (splits > 1 && kernel != 0 && border_out && (K % 64) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 &&
+      !(((uintptr_t)A | (uintptr_t)Bw) & 15)) {
+    GemmArgs g = {A, lda, Bw, ldb, (void*)dx_ext_buf, N, M, N, K, nullptr, nullptr, 0, MH_GEMM_OUT_F32, 1.0f, 1, K / 64, 0L};
+    g.flags |= plan_variant(kernel) << MH_GEMM_VARIANT_SHIFT;
+    const int nt = K / 64;                          // the split count run_splitk will settle on
+    int sp = splits > nt ? nt : splits;
+    const int tps = (nt + sp - 1) / sp;
+    sp = (nt + tps - 1) / tps;
+    float* wsp = ws_for(stream);
+    const int rc = run_splitk(g, splits, wsp, stream, /*reduce=*/false);
+    if (rc) return rc;
+    return mh_launch_lora_dx(wsp, N, sp, (long)M * N, loraA, dxn, border_out, M, D, R2, s, p, seed, stream);
+  }
+  if (!dx_ext_buf) return MH_ERR_ARG;
+  const int rc = mh_gemm_bf16_nt(A, lda, Bw, ldb, dx_ext_buf, N, M, N, K, nullptr, nullptr, 0, MH_GEMM_OUT_F32, 1.0f, stream);
+  if (rc) return rc;
+  return mh_launch_lora_dx(dx_ext_buf, N, 1, 0, loraA, dxn, nullptr, M, D, R2, s, p, seed, stream);
+}
+
 int mh_launch_attn_rope_bwd(const void* qkv, int ld, const void* o, int ldo, const void* dout, int dout_is_bf16, int nslab,
                             long slab, int ldd, const float* lse, void* dqkv, const int* pos, const float* cos_tab,
                             const float* sin_tab, const int* kv_len, int B, int H, int S, int D, float scale,

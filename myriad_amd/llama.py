@@ -227,9 +227,9 @@ class LlamaHIP:
             if self.lora is None:
                 dxn = ops.gemm(dqkv, L["wqkvT"], out_dtype=F32)
             else:
-                dx_ext = ops.gemm(dqkv, L["wqkvT_ext"], out_dtype=F32)      # [M, D+64]: base dgrad | d(s*t)
-                dxn = self.lora.backward(li, dx_ext, dqkv, lsave[0], lsave[1], lsave[2],
-                                         defer_wgrad=self.defer_lora_wgrad)
+                # [M, D+64] = base dgrad | d(s*t), and the LoRA correction of dxn, in one call (split-K slabs summed in the dx kernel)
+                dxn = self.lora.backward_from_dqkv(li, dqkv, L["wqkvT_ext"], lsave[0], lsave[1], lsave[2],
+                                                   defer_wgrad=self.defer_lora_wgrad)
             dh, dh_b = ops.rmsnorm_bwd(dxn, h_in, L["ln1"], self.eps, dres=dh2, want_bf16=True)
         self._saved = None
         if self.lora is not None:

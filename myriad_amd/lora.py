@@ -132,10 +132,7 @@ class LoraQV:
         dA_q, dA_v, dB_q, dB_v into the flat gradient buffer.  The weight gradients feed nothing but the optimiser, so with
         defer_wgrad they are only queued: run_deferred_wgrads() launches them on a side stream beside whatever the caller
         does next (the Q-Former / adapter backward) and join_wgrads() makes the current stream wait for them."""
-        if defer_wgrad:
-            self._deferred.append((layer_idx, dx_ext, dqkv, x_ext, p, seed))
-        else:
-            self._wgrad(layer_idx, dx_ext, dqkv, x_ext, p, seed)
+        self._queue_wgrad(layer_idx, (dx_ext, dx_ext.data_ptr(), dx_ext.stride(0)), dqkv, x_ext, p, seed, defer_wgrad)
         D, r = self.D, self.r
         M = dx_ext.shape[0]
         A = self._aqv(self.P, layer_idx)
@@ -144,13 +141,42 @@ class LoraQV:
                                           p, seed, ops._s()), "mh_lora_dx")
         return dxn
 
-    def _wgrad(self, layer_idx, dx_ext, dqkv, x_ext, p, seed) -> None:
+    def backward_from_dqkv(self, layer_idx: int, dqkv: torch.Tensor, wqkvT_ext: torch.Tensor, x_ext: torch.Tensor, p: float,
+                           seed: int, defer_wgrad: bool = False) -> torch.Tensor:
+        """The dgrad GEMM dqkv . [W | B_ext] and backward() in one library call (mh_gemm_lora_dx): when the GEMM policy splits
+        K -- it does at the training shapes -- the dx kernel sums the fp32 partial slabs itself, so neither the reduce launch
+        nor the [M, D+64] fp32 product exists; only the summed 64-column border is kept for the weight gradients."""
+        D, r = self.D, self.r
+        M, K = dqkv.shape
+        _, splits = ops.gemm_plan(M, D + BORDER, K)
+        A = self._aqv(self.P, layer_idx)
+        dxn = torch.empty((M, D), dtype=F32, device=self.dev)
+        if splits > 1:
+            border = torch.empty((M, BORDER), dtype=F32, device=self.dev)
+            keep, gptr, ldg, buf_ptr = border, border.data_ptr() - 4 * D, BORDER, None     # the kernels address the border at column D
+        else:
+            buf = torch.empty((M, D + BORDER), dtype=F32, device=self.dev)
+            keep, gptr, ldg, buf_ptr, border = buf, buf.data_ptr(), buf.stride(0), buf.data_ptr(), None
+        _lib.check(_lib.load().mh_gemm_lora_dx(dqkv.data_ptr(), dqkv.stride(0), wqkvT_ext.data_ptr(), wqkvT_ext.stride(0), buf_ptr,
+                                               A.data_ptr(), dxn.data_ptr(), None if border is None else border.data_ptr(), M, D, K,
+                                               2 * r, self.s, p, seed, ops._s()), f"mh_gemm_lora_dx M={M} K={K}")
+        self._queue_wgrad(layer_idx, (keep, gptr, ldg), dqkv, x_ext, p, seed, defer_wgrad)
+        return dxn
+
+    def _queue_wgrad(self, layer_idx, g, dqkv, x_ext, p, seed, defer_wgrad) -> None:
+        if defer_wgrad:
+            self._deferred.append((layer_idx, g, dqkv, x_ext, p, seed))
+        else:
+            self._wgrad(layer_idx, g, dqkv, x_ext, p, seed)
+
+    def _wgrad(self, layer_idx, g, dqkv, x_ext, p, seed) -> None:
+        """g = (tensor that owns the memory, address of a [M, >= D+2r] f32 view whose columns D.. hold d(s*t), its row stride)."""
         D, r, W = self.D, self.r, self.D
-        M = dx_ext.shape[0]
+        M = dqkv.shape[0]
         _, _, nb_q, nb_v = self.names(layer_idx)
         gA = self._aqv(self.G, layer_idx)
         dv = dqkv[:, 2 * W:]
-        _lib.check(_lib.load().mh_lora_wgrad(x_ext.data_ptr(), x_ext.stride(0), dx_ext.data_ptr(), dx_ext.stride(0),
+        _lib.check(_lib.load().mh_lora_wgrad(x_ext.data_ptr(), x_ext.stride(0), g[1], g[2],
                                              dqkv.data_ptr(), dv.data_ptr(), dqkv.stride(0), x_ext[:, D:].data_ptr(),
                                              x_ext.stride(0), gA.data_ptr(), self.G[nb_q].data_ptr(), self.G[nb_v].data_ptr(),
                                              self._ws.data_ptr(), M, D, 2 * r, self.s, p, seed, ops._s()), "mh_lora_wgrad")
@@ -164,10 +190,10 @@ class LoraQV:
         main = torch.cuda.current_stream()
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side):
-            for (li, dx_ext, dqkv, x_ext, p, seed) in self._deferred:
-                for t in (dx_ext, dqkv):
+            for (li, g, dqkv, x_ext, p, seed) in self._deferred:
+                for t in (g[0], dqkv):
                     t.record_stream(self._side)          # allocated on the main stream, read here
-                self._wgrad(li, dx_ext, dqkv, x_ext, p, seed)
+                self._wgrad(li, g, dqkv, x_ext, p, seed)
             self._wgrad_ev = torch.cuda.Event()
             self._wgrad_ev.record()
         self._deferred = []

@@ -432,6 +432,38 @@ def test_ve_net_grads_vs_bf16_forward_emulation():
 
 
 # ------------------------------------------------------------------------------------------------ PEFT LoRA (a-14)
+def test_lora_backward_fused_with_the_qkv_dgrad_is_bit_identical():
+    """mh_gemm_lora_dx (split-K slabs summed inside the LoRA dx kernel, border kept for the weight gradients) against the
+    two-call form gemm(out f32) + mh_lora_dx + mh_lora_wgrad: same dxn, same dA / dB, bit for bit, at the training shape."""
+    from myriad_amd.lora import BORDER, LoraQV, lora_param_specs
+    from myriad_amd.myriad import ParamStore
+    ops.ensure_workspace(torch.device(DEV))
+    D, r, M = 4096, 8, 1184
+    assert ops.gemm_plan(M, D + BORDER, 3 * D)[1] > 1          # the policy splits K here: the slab path is what runs
+    gen = torch.Generator().manual_seed(77)
+    outs = []
+    for fused in (False, True):
+        st = ParamStore(lora_param_specs(1, D, r), DEV)
+        g2 = torch.Generator().manual_seed(78)
+        for name, ishape, _ in st.specs:
+            st.p[name].copy_(torch.randn(ishape, generator=g2) * 0.05)
+        lora = LoraQV(1, D, r, 16.0, 0.05, st.p, st.g, DEV)
+        gen.manual_seed(79)
+        dqkv = (torch.randn(M, 3 * D, generator=gen) * 0.02).to(DEV).to(torch.bfloat16)
+        wT = (torch.randn(D + BORDER, 3 * D, generator=gen) * 0.02).to(DEV).to(torch.bfloat16)
+        x_ext = (torch.randn(M, D + BORDER, generator=gen) * 0.5).to(DEV).to(torch.bfloat16)
+        seed = 123456789
+        if fused:
+            dxn = lora.backward_from_dqkv(0, dqkv, wT, x_ext, 0.05, seed)
+        else:
+            dx_ext = ops.gemm(dqkv, wT, out_dtype=torch.float32)
+            dxn = lora.backward(0, dx_ext, dqkv, x_ext, 0.05, seed)
+        torch.cuda.synchronize()
+        outs.append((dxn.clone(), st.flat_g.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    assert torch.equal(outs[0][1], outs[1][1]) and float(outs[0][1].abs().sum()) > 0
+
+
 @pytest.mark.parametrize("dropout", [0.0, 0.05])
 def test_llama_lora_qv_vs_oracle(dropout):
     """q/v LoRA as a K-border of the qkv GEMM vs the oracle's restated peft formula (parity unpinned by the

@@ -163,6 +163,9 @@ int mh_lora_wgrad(const void* x, long ldx, const float* dx_ext, long ldg, const 
                   float s, float p, unsigned long long seed, mh_stream_t st);
 int mh_lora_refresh_border(const float* Bq, const float* Bv, void* ext, long ld_ext, void* extT, long ld_extT, int W,
                            int D, int r, mh_stream_t st);
+/* The same for every layer in one launch: table = device array of n_layers x {B_q, B_v, W_ext, W_ext^T or NULL} pointers
+ * (4 x 8 bytes per layer), all layers sharing the two row strides. */
+int mh_lora_refresh_borders(const void* table, int n_layers, long ld_ext, long ld_extT, int W, int D, int r, mh_stream_t stream);
 
 /* K10 rank-r adaptor y = x + (x A^T) B^T (networks.py:81-93), f32, r in {1,2,4,8}. */
 int mh_lowrank_fwd(const float* x, const float* A, const float* Bm, float* y, float* t, int M, int D, int R,

@@ -180,18 +180,45 @@ extern "C" int mh_relu_maxpool2_bwd(const float* dp, const void* y, int y_is_f32
 // pack: Wp[co][k] = bf16(W[co][k]) k<K ; Wp[co][K] = bias[co] ; rest 0
 __global__ void conv_pack_kernel(const float* __restrict__ Wt, const float* __restrict__ bias, bf16_t* __restrict__ Wp,
                                  int Cout, int K, int Kpad) {
-  const long total = (long)Cout * Kpad;
+  // one thread per 8 packed elements (Kpad % 64 == 0): a 16-byte store, and two 16-byte loads where the row allows it
+  const int cpr = Kpad >> 3;
+  const long total = (long)Cout * cpr;
+  const bool vec = (K & 3) == 0;
   for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
-    const int co = (int)(it / Kpad), k = (int)(it - (long)co * Kpad);
-    float v = 0.f;
-    if (k < K) v = Wt[(long)co * K + k];
-    else if (k == K) v = bias ? bias[co] : 0.f;
-    Wp[it] = f2bf(v);
+    const int co = (int)(it / cpr), k0 = (int)(it - (long)co * cpr) * 8;
+    float v[8];
+    if (vec && k0 + 8 <= K) {
+      const float4_t a = *reinterpret_cast<const float4_t*>(Wt + (long)co * K + k0);
+      const float4_t b = *reinterpret_cast<const float4_t*>(Wt + (long)co * K + k0 + 4);
+      v[0] = a[0]; v[1] = a[1]; v[2] = a[2]; v[3] = a[3]; v[4] = b[0]; v[5] = b[1]; v[6] = b[2]; v[7] = b[3];
+    } else {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const int k = k0 + e;
+        v[e] = k < K ? Wt[(long)co * K + k] : (k == K && bias ? bias[co] : 0.f);
+      }
+    }
+    uint4 pk;
+    pk.x = pack_bf2(v[0], v[1]); pk.y = pack_bf2(v[2], v[3]); pk.z = pack_bf2(v[4], v[5]); pk.w = pack_bf2(v[6], v[7]);
+    *reinterpret_cast<uint4*>(Wp + (long)co * Kpad + k0) = pk;
   }
 }
 // unpack gradients: dW[co][k] = dWp[co][k], db[co] = dWp[co][K]
 __global__ void conv_unpack_kernel(const float* __restrict__ dWp, float* __restrict__ dW, float* __restrict__ db,
                                    int Cout, int K, int Kpad) {
+  if ((K & 3) == 0) {                               // 16-byte copies; the bias column is element K of each packed row
+    const int qpr = K >> 2;
+    const long total = (long)Cout * (qpr + 1);
+    for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+      const int co = (int)(it / (qpr + 1)), q = (int)(it - (long)co * (qpr + 1));
+      if (q == qpr) {
+        if (db) db[co] = dWp[(long)co * Kpad + K];
+      } else {
+        *reinterpret_cast<float4_t*>(dW + (long)co * K + q * 4) = *reinterpret_cast<const float4_t*>(dWp + (long)co * Kpad + q * 4);
+      }
+    }
+    return;
+  }
   const long total = (long)Cout * (K + 1);
   for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
     const int co = (int)(it / (K + 1)), j = (int)(it - (long)co * (K + 1));
@@ -205,8 +232,8 @@ __global__ void conv_unpack_kernel(const float* __restrict__ dWp, float* __restr
 
 extern "C" int mh_conv_pack_weight(const float* W, const float* bias, void* Wp, int Cout, int K, int Kpad,
                                    hipStream_t stream) {
-  if (Kpad < K + 1) return MH_ERR_ARG;
-  hipLaunchKernelGGL(conv_pack_kernel, dim3(cv_grid((long)Cout * Kpad)), dim3(CV_NT), 0, stream, W, bias,
+  if (Kpad < K + 1 || (Kpad & 7) != 0) return MH_ERR_ARG;
+  hipLaunchKernelGGL(conv_pack_kernel, dim3(cv_grid((long)Cout * (Kpad / 8))), dim3(CV_NT), 0, stream, W, bias,
                      (bf16_t*)Wp, Cout, K, Kpad);
   MH_CHECK_LAUNCH();
   return MH_OK;
@@ -214,7 +241,7 @@ extern "C" int mh_conv_pack_weight(const float* W, const float* bias, void* Wp, 
 extern "C" int mh_conv_unpack_grad(const float* dWp, float* dW, float* db, int Cout, int K, int Kpad,
                                    hipStream_t stream) {
   if (Kpad < K + 1) return MH_ERR_ARG;
-  hipLaunchKernelGGL(conv_unpack_kernel, dim3(cv_grid((long)Cout * (K + 1))), dim3(CV_NT), 0, stream, dWp, dW, db,
+  hipLaunchKernelGGL(conv_unpack_kernel, dim3(cv_grid((K & 3) ? (long)Cout * (K + 1) : (long)Cout * (K / 4 + 1))), dim3(CV_NT), 0, stream, dWp, dW, db,
                      Cout, K, Kpad);
   MH_CHECK_LAUNCH();
   return MH_OK;

@@ -271,6 +271,22 @@ __global__ void lora_refresh_kernel(const float* __restrict__ Bq, const float* _
   }
 }
 
+// all layers in one launch: tab[layer] = {B_q, B_v, W_ext, W_ext^T (or NULL)} device pointers, blockIdx.y = layer
+struct LoraRefreshEntry { const float* Bq; const float* Bv; bf16_t* ext; bf16_t* extT; };
+__global__ void lora_refresh_all_kernel(const LoraRefreshEntry* __restrict__ tab, long ld_ext, long ld_extT, int W, int D, int r) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // i = n*r + j
+  if (i >= W * r) return;
+  const LoraRefreshEntry e = tab[blockIdx.y];
+  const int n = i / r, j = i - n * r;
+  const bf16_t q = f2bf(e.Bq[i]), v = f2bf(e.Bv[i]);
+  e.ext[(long)n * ld_ext + D + j] = q;
+  e.ext[(long)(2 * W + n) * ld_ext + D + r + j] = v;
+  if (e.extT) {
+    e.extT[(long)(D + j) * ld_extT + n] = q;
+    e.extT[(long)(D + r + j) * ld_extT + 2 * W + n] = v;
+  }
+}
+
 #define LORA_DISPATCH(R2_, CALL)                      \
   switch (R2_) {                                      \
     case 16: { constexpr int R2 = 16; CALL; break; }  \
@@ -328,6 +344,16 @@ extern "C" int mh_lora_wgrad(const void* x, long ldx, const float* dx_ext, long 
   const int nA = R2_ * D, nB = D * r;
   hipLaunchKernelGGL(lora_wgrad_reduce_kernel, dim3((nA + 255) / 256), dim3(256), 0, stream, pA, pBq, pBv, dA, dBq, dBv, nA,
                      nB);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+extern "C" int mh_lora_refresh_borders(const void* table, int n_layers, long ld_ext, long ld_extT, int W, int D, int r,
+                                       hipStream_t stream) {
+  if (n_layers <= 0) return MH_OK;
+  if (!table || W <= 0 || r <= 0) return MH_ERR_ARG;
+  hipLaunchKernelGGL(lora_refresh_all_kernel, dim3((W * r + 255) / 256, n_layers), dim3(256), 0, stream,
+                     (const LoraRefreshEntry*)table, ld_ext, ld_extT, W, D, r);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

@@ -98,17 +98,23 @@ class LoraQV:
         return self._xext[key]
 
     def refresh(self, layers: List[dict]) -> None:
-        """Per optimisation step: push the current fp32 B_q / B_v into the bf16 borders of W_ext and W_ext^T."""
+        """Per optimisation step: push the current fp32 B_q / B_v into the bf16 borders of W_ext and W_ext^T -- one launch for
+        all layers over a device table of their (fixed) addresses."""
         D, r, W = self.D, self.r, self.D
-        L = _lib.load()
-        s = ops._s()
-        for i, Lr in enumerate(layers):
-            _, _, nbq, nbv = self.names(i)
-            ext, extT = Lr["wqkv_ext"], Lr.get("wqkvT_ext")
-            _lib.check(L.mh_lora_refresh_border(self.P[nbq].data_ptr(), self.P[nbv].data_ptr(), ext.data_ptr(),
-                                                ext.stride(0), None if extT is None else extT.data_ptr(),
-                                                0 if extT is None else extT.stride(0), W, D, r, s),
-                       "mh_lora_refresh_border")
+        key = tuple(id(Lr) for Lr in layers)
+        if getattr(self, "_refresh_key", None) != key:
+            ptrs, lds = [], set()
+            for i, Lr in enumerate(layers):
+                _, _, nbq, nbv = self.names(i)
+                ext, extT = Lr["wqkv_ext"], Lr.get("wqkvT_ext")
+                ptrs += [self.P[nbq].data_ptr(), self.P[nbv].data_ptr(), ext.data_ptr(), 0 if extT is None else extT.data_ptr()]
+                lds.add((ext.stride(0), 0 if extT is None else extT.stride(0)))
+            if len(lds) != 1:
+                raise _lib.MyriadHipError("lora.refresh: layers with different W_ext strides")
+            self._refresh_tab = torch.tensor(ptrs, dtype=torch.int64).to(self.dev)
+            self._refresh_ld, self._refresh_key = lds.pop(), key
+        _lib.check(_lib.load().mh_lora_refresh_borders(self._refresh_tab.data_ptr(), len(layers), self._refresh_ld[0],
+                                                       self._refresh_ld[1], W, D, r, ops._s()), "mh_lora_refresh_borders")
 
     def _seed(self, layer_idx: int) -> int:
         return (self.base_seed * 0x9E3779B97F4A7C15 + self.step_seed * 1315423911 + layer_idx * 2654435761 + 12345) \

@@ -184,6 +184,11 @@ int mh_argmax_rows(const float* logits, long ldl, long* out, float* margin, int 
    `do_sample=True, top_p=p` is the arg-max (p_max >= p keeps exactly one token) -- generation_kwargs of the eval script */
 int mh_argmax_pmax_rows(const float* logits, long ldl, long* out, float* margin, float* pmax, int R, int V, int ban_id,
                         float inv_temp, mh_stream_t s);
+/* end of a decode step on the device: rec[3][R] f32 = (ids, margins, p_max) of this step in one small record, next_ids = ids
+   (the next step's input: myriad.py:433-454's feed-back of the generated token), *step += 1 -- the token step needs no host
+   input and the host fetches a step with one copy */
+int mh_decode_record(const long* nxt, const float* margin, const float* pmax, float* rec, long* next_ids, int* step, int R,
+                     mh_stream_t s);
 
 /* K12 conv stacks of VEInstructorV2 / VETokenizer (networks.py:98-127,159-189) as im2col + mh_gemm_bf16_nt. */
 int mh_im2col_nhwc(const void* x, void* col, int B, int H, int W, int C, int kh, int kw, int pad, int Kpad,

@@ -123,6 +123,31 @@ __global__ __launch_bounds__(LNT) void pmax_kernel(const float* __restrict__ log
   s = block_sum<LNW>(s, red);
   if (threadIdx.x == 0) pmax[row] = 1.f / s;
 }
+// End of a decode step on the device: the picked ids become the next step's input ids (the token step then needs nothing
+// from the host and is a fixed hipGraph), the step's results are packed into ONE small record rec[3][R] f32 = (id, margin,
+// p_max) -- ids < 2^24 are exact in fp32 -- so the host fetches a step with a single copy, and the step counter advances.
+// (Writing the record straight into pinned host memory was measured: a kernel that stores to host memory ends with a
+// system-scope release, +0.2 ms per token.)
+__global__ void decode_record_kernel(const long* __restrict__ nxt, const float* __restrict__ margin, const float* __restrict__ pmax,
+                                     float* __restrict__ rec, long* __restrict__ next_ids, int* __restrict__ step, int R) {
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
+    const long id = nxt[r];
+    rec[r] = (float)id;
+    rec[R + r] = margin[r];
+    rec[2 * R + r] = pmax[r];
+    next_ids[r] = id;
+  }
+  if (threadIdx.x == 0) *step += 1;
+}
+extern "C" int mh_decode_record(const long* nxt, const float* margin, const float* pmax, float* rec, long* next_ids, int* step,
+                                int R, hipStream_t stream) {
+  if (R <= 0) return MH_OK;
+  if (!nxt || !margin || !pmax || !rec || !next_ids || !step) return MH_ERR_ARG;
+  hipLaunchKernelGGL(decode_record_kernel, dim3(1), dim3(64), 0, stream, nxt, margin, pmax, rec, next_ids, step, R);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
 extern "C" int mh_argmax_pmax_rows(const float* logits, long ldl, long* out, float* margin, float* pmax, int R, int V,
                                    int ban_id, float inv_temp, hipStream_t stream) {
   if (R <= 0) return MH_OK;

@@ -663,6 +663,13 @@ def argmax_pmax_rows(logits: torch.Tensor, out, margin_out, pmax_out, ban_id: in
     return out, margin_out, pmax_out
 
 
+def decode_record(nxt, margin, pmax, rec, next_ids, step_dev):
+    """rec[3, R] = this step's (ids, margins, p_max) as f32; next_ids = ids; step += 1 -- all on the device (graph-replayable)."""
+    R = nxt.numel()
+    _lib.check(_L().mh_decode_record(_p(nxt), _p(margin), _p(pmax), _p(rec), _p(next_ids), _p(step_dev), R, _s()),
+               "mh_decode_record")
+
+
 # --------------------------------------------------------------------------- conv stack pieces
 def im2col(x_nhwc: torch.Tensor, kh: int, kw: int, pad: int):
     B, H, W, C = x_nhwc.shape

@@ -90,7 +90,6 @@ class LlamaHIP:
         # (55.7 -> 55.1 ms per step: they run beside the Q-Former backward); MYRIAD_LORA_DEFER=0 computes them in place
         self.defer_lora_wgrad = os.environ.get("MYRIAD_LORA_DEFER", "1") != "0"
         self._packed = None
-        self._decode_ws = {}
 
     def _pack_for_decode(self) -> None:
         """(Re)build the packed copies the single-token step streams.  Frozen matrices are packed once; the bordered qkv
@@ -283,29 +282,6 @@ class LlamaHIP:
             h = lin(li, "wd", act, residual=h2, out_dtype=F32)
         return h
 
-    def _decode_workspace(self, B: int, T_need: int, inv_temp: float):
-        """Buffers (and, once captured, the hipGraph) of the single-token step for a batch size: KV caches, device-resident
-        counters, id / logit / result buffers and per-step histories.  Kept across generate() calls -- an evaluation run
-        calls generate() once per batch, and re-capturing ~290 launches each time cost ~9 ms per call."""
-        T_cap = ops.round_up(T_need + 2, 64)
-        key = (B, T_cap, float(inv_temp), id(self._packed), None if self._packed is None else self._packed.get("qkv_key"),
-               self.lora is not None)
-        ws = self._decode_ws.get(key)
-        if ws is None:
-            if len(self._decode_ws) >= 3:                               # a few shapes at most: evict the oldest
-                self._decode_ws.pop(next(iter(self._decode_ws)))
-            dev, i32 = self.dev, torch.int32
-            ws = dict(T=T_cap, graph=None, warm=False,
-                      caches=[torch.zeros((B, T_cap, 2 * self.D), dtype=BF16, device=dev) for _ in self.layers],
-                      pos=torch.zeros((B,), dtype=i32, device=dev), kvlen=torch.zeros((B,), dtype=i32, device=dev),
-                      ids=torch.zeros((B,), dtype=torch.long, device=dev), x_in=torch.empty((B, self.D), dtype=F32, device=dev),
-                      logits=torch.empty((B, self.V), dtype=F32, device=dev),
-                      nxt=torch.empty((B,), dtype=torch.long, device=dev), mar=torch.empty((B,), dtype=F32, device=dev),
-                      pmx=torch.empty((B,), dtype=F32, device=dev), step=torch.zeros((1,), dtype=i32, device=dev),
-                      rec=torch.zeros((3, B), dtype=F32, device=dev))
-            self._decode_ws[key] = ws
-        return ws
-
     @torch.no_grad()
     def greedy_generate(self, inputs_embeds: torch.Tensor, max_new_tokens: int = 90,
                         stop_ids=((835,), (2277, 29937)), eos_id: int = 2, min_length: int = 1,
@@ -314,22 +290,18 @@ class LlamaHIP:
         """Decode from [B,S0,D] f32 embeddings with a KV cache (prefill + 1-token steps).  Same contract
         as the oracle's greedy_generate: stop when ROW 0 ends with a stop sequence (conversation.py:102-107),
         EOS banned while fewer than `min_length` tokens were generated, finished rows padded with EOS.
-
-        The single-token step (~290 launches) is captured into a hipGraph once per batch size, kept across generate() calls
-        (an evaluation run calls generate() once per batch) and replayed; everything it needs lives on the device -- position /
-        valid-length counters, and the token it just picked is fed back as the next input by the step itself
-        (mh_decode_record), which packs the step's picks into one small record: between two steps the host makes ONE
-        device->host copy.  (Measured and dropped: launching step t+1 before reading step t -- back-to-back launches of one
-        executable graph cost more than the host's 0.07 ms per step; writing the record straight into pinned host memory --
-        +0.2 ms per token.)
+        The single-token step is launch-bound (~420 kernels per token), so after one eager step it is captured
+        into a hipGraph and replayed: position / valid-length counters live in device memory.
 
         `do_sample=True, top_p, temperature` are the eval script's arguments (evaluation_aqa_dataset.py:289-301).  HF's
         top-p warper keeps the smallest descending-probability set whose mass reaches top_p (at least one token), so a
         step whose p_max >= top_p IS the arg-max; the kernel reports p_max per row and only a row below the threshold is
         drawn on the host from that row's logits (a genuine sample: reproducible here through `generator`, never
-        bit-comparable with another framework's RNG) and replaces the fed-back id.  `last_generate_stats` counts such steps."""
+        bit-comparable with another framework's RNG).  `last_generate_stats` counts such steps."""
         B, S0, D = inputs_embeds.shape
+        T = S0 + max_new_tokens
         scale = 1.0 / math.sqrt(self.hd)
+        caches = [torch.zeros((B, T, 2 * self.D), dtype=BF16, device=self.dev) for _ in self.layers]
         out_ids, margins = [], []
         unfinished = torch.ones(B, dtype=torch.long)
         inv_temp = 1.0 / float(temperature) if do_sample else 1.0
@@ -339,14 +311,21 @@ class LlamaHIP:
             self.lora.refresh(self.layers)
         if self.pack_decode and B <= 16:
             self._pack_for_decode()
-        elif not self.pack_decode:
-            self._packed = None                                      # MYRIAD_PACK_DECODE=0: stream the row-major matrices
-        ws = self._decode_workspace(B, S0 + max_new_tokens, inv_temp)
-        caches = ws["caches"]
+        else:
+            self._packed = None
 
-        def sample_row(logits_row: torch.Tensor, ban: int) -> int:
+        nxt_out = torch.empty((B,), dtype=torch.long, device=self.dev)
+        mar_out = torch.empty((B,), dtype=F32, device=self.dev)
+        pmx_out = torch.empty((B,), dtype=F32, device=self.dev)
+        logits_ref = [None]
+
+        def pick(logits, ban):
+            logits_ref[0] = logits
+            ops.argmax_pmax_rows(logits, nxt_out, mar_out, pmx_out, ban_id=ban, inv_temp=inv_temp)
+
+        def sample_row(row: int, ban: int) -> int:
             """HF TopPLogitsWarper + multinomial on one row (host)."""
-            lg = logits_row.float().cpu() * inv_temp
+            lg = logits_ref[0][row].float().cpu() * inv_temp
             if ban >= 0:
                 lg[ban] = float("-inf")
             srt, idx = torch.sort(lg, descending=False)
@@ -357,81 +336,69 @@ class LlamaHIP:
             probs = torch.zeros_like(lg).scatter(0, idx, srt.softmax(-1))
             return int(torch.multinomial(probs, 1, generator=generator))
 
-        def record(nxt: torch.Tensor, mar: torch.Tensor, pm: torch.Tensor, ban: int, logits_of=None):
-            """Host bookkeeping of one step's picks.  Returns (done, redrawn): redrawn = a live row was re-drawn on the host
-            (finished rows are fed their raw arg-max instead of EOS by the device: rows are independent and their outputs are
-            overwritten with EOS here)."""
+        def record(ban: int):
             nonlocal unfinished
-            margins.append(mar)
+            nxt = nxt_out.cpu()
+            margins.append(mar_out.cpu())
             stats["steps"] += 1
-            redrawn = False
             if do_sample:
+                pm = pmx_out.cpu()
                 stats["min_pmax"] = min(stats["min_pmax"], float(pm[unfinished.bool()].min()) if int(unfinished.sum()) else 1.0)
                 for row in range(B):
                     if int(unfinished[row]) and float(pm[row]) < top_p:
-                        nxt[row] = sample_row(logits_of()[row], ban)
+                        nxt[row] = sample_row(row, ban)
                         stats["sampled_rows"] += 1
-                        redrawn = True
             nxt = nxt * unfinished + eos_id * (1 - unfinished)       # HF pads finished rows with pad(=eos)
             unfinished = unfinished * (nxt != eos_id).long()
             out_ids.append(nxt)
             row0 = [int(t[0]) for t in out_ids]
             if any(len(row0) >= len(st) and row0[-len(st):] == list(st) for st in stop_ids):
-                return True, redrawn
-            return int(unfinished.max()) == 0, redrawn
+                return True
+            return int(unfinished.max()) == 0
 
-        # ---- prefill (eager, host-known lengths)
+        # ---- prefill
         pos = torch.arange(S0, dtype=torch.int32).repeat(B).to(self.dev)
         h = self._decode_block(inputs_embeds.reshape(B * S0, D).contiguous(), B, S0, caches, scale, pos, past=0)
         last = h.view(B, S0, D)[:, -1].contiguous()
-        logits0 = ops.gemm(ops.rmsnorm_fwd(last, self.norm, self.eps), self.lm_head, out_dtype=F32)
+        logits = ops.gemm(ops.rmsnorm_fwd(last, self.norm, self.eps), self.lm_head, out_dtype=F32)
         ban0 = eos_id if 0 < min_length else -1
-        ops.argmax_pmax_rows(logits0, ws["nxt"], ws["mar"], ws["pmx"], ban_id=ban0, inv_temp=inv_temp)
-        done, _ = record(ws["nxt"].cpu(), ws["mar"].cpu(), ws["pmx"].cpu(), ban0, logits_of=lambda: logits0)
+        pick(logits, ban0)
+        done = record(ban0)
 
-        # ---- single-token steps: everything the step reads is on the device
-        ws["pos"].fill_(S0)                                          # position of the incoming token
-        ws["kvlen"].fill_(S0 + 1)                                    # valid keys after the append
-        ws["step"].zero_()
+        # ---- single-token steps; device-resident counters
+        pos_dev = torch.full((B,), S0, dtype=torch.int32, device=self.dev)        # position of the incoming token
+        kvlen_dev = torch.full((B,), S0 + 1, dtype=torch.int32, device=self.dev)  # valid keys after the append
+        ids_dev = torch.empty((B,), dtype=torch.long, device=self.dev)
+        x_in = torch.empty((B, D), dtype=F32, device=self.dev)
+        lg_buf = torch.empty((B, self.V), dtype=F32, device=self.dev)             # fixed address: the graph writes it
 
         def token_step(ban):
-            ops.embed_gather(self.embed, ws["ids"], ws["x_in"])
-            hh = self._decode_block(ws["x_in"], B, 1, caches, scale, ws["pos"], pos_dev=ws["pos"], kvlen_dev=ws["kvlen"])
+            ops.embed_gather(self.embed, ids_dev, x_in)
+            hh = self._decode_block(x_in, B, 1, caches, scale, pos_dev, pos_dev=pos_dev, kvlen_dev=kvlen_dev)
             hn = ops.rmsnorm_fwd(hh, self.norm, self.eps)
-            if self._packed is not None and B <= 16:
-                ops.gemv_packed(hn, self._packed["lm_head"], out=ws["logits"], out_dtype=F32)
+            if self._packed is not None:
+                ops.gemv_packed(hn, self._packed["lm_head"], out=lg_buf, out_dtype=F32)
             else:
-                ops.gemm(hn, self.lm_head, out=ws["logits"])
-            ops.argmax_pmax_rows(ws["logits"], ws["nxt"], ws["mar"], ws["pmx"], ban_id=ban, inv_temp=inv_temp)
-            ops.decode_record(ws["nxt"], ws["mar"], ws["pmx"], ws["rec"], ws["ids"], ws["step"])
-            ops.add_i32_(ws["pos"], 1)
-            ops.add_i32_(ws["kvlen"], 1)
+                ops.gemm(hn, self.lm_head, out=lg_buf)
+            pick(lg_buf, ban)
+            ops.add_i32_(pos_dev, 1)
+            ops.add_i32_(kvlen_dev, 1)
 
-        def launch(ban):
-            """Enqueue one token step: a replay of the captured graph when there is one."""
-            if ban == -1 and use_graph and ws["graph"] is not None:
-                ws["graph"].replay()
-                return
-            token_step(ban)
-            if ban == -1 and use_graph and ws["warm"]:
-                # the eager step above was this batch size's second: capture the next one (kernels are warm, buffers fixed)
-                torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                    token_step(-1)
-                ws["graph"] = g
-            ws["warm"] = True
-
-        step = 1                                                     # tokens generated so far (= index of the next one)
-        if not done and step < max_new_tokens:
-            ws["ids"].copy_(out_ids[-1].to(self.dev))
+        graph = None
+        step = 1
         while not done and step < max_new_tokens:
+            ids_dev.copy_(out_ids[-1].to(self.dev))
             ban = eos_id if step < min_length else -1
-            launch(ban)
-            rec = ws["rec"].cpu()                                    # the one device->host copy of the step (it also waits for it)
-            done, redrawn = record(rec[0].long(), rec[1].clone(), rec[2].clone(), ban, logits_of=lambda: ws["logits"])
-            if redrawn and not done:
-                ws["ids"].copy_(out_ids[-1].to(self.dev))            # a host draw replaces the arg-max the step fed back to itself
+            if graph is not None:
+                graph.replay()
+            else:
+                token_step(ban)
+                if use_graph and ban == -1 and max_new_tokens - step > 4:
+                    torch.cuda.synchronize()
+                    graph = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(graph):
+                        token_step(-1)
+            done = record(ban)
             step += 1
         ids = torch.stack(out_ids, 1)
         if return_margins:

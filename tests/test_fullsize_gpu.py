@@ -107,6 +107,32 @@ def test_graph_replayed_decode_equals_eager_decode(model):
         model.train()
 
 
+def test_decode_graph_and_buffers_survive_across_generate_calls(model):
+    """The token-step graph, KV caches and device counters are kept per batch size and re-used by later generate() calls:
+    interleaved calls with different prompts, lengths and batch sizes must give exactly the tokens a fresh state gives."""
+    model.eval()
+    try:
+        kw = dict(stop_ids=((-1,),), min_length=0, eos_token_id=-5)
+        strip = lambda d: {k: v for k, v in d.items() if k not in ("target_ids", "target_mask")}
+        a_in, b_in, c_in = strip(samples(2, seed=21)), strip(samples(2, seed=22)), strip(samples(1, seed=23))
+        llm = model.llama
+
+        def fresh(inp, n):
+            llm._decode_ws.clear()
+            return model.generate(inp, max_new_tokens=n, **kw)["token_ids"]
+
+        ref_a, ref_b, ref_c, ref_a_long = fresh(a_in, 10), fresh(b_in, 10), fresh(c_in, 10), fresh(a_in, 40)
+        llm._decode_ws.clear()
+        seq = [(a_in, 10, ref_a), (b_in, 10, ref_b), (c_in, 10, ref_c), (a_in, 10, ref_a), (a_in, 40, ref_a_long), (b_in, 10, ref_b)]
+        for inp, n, want in seq:
+            got = model.generate(inp, max_new_tokens=n, **kw)["token_ids"]
+            assert torch.equal(got, want)
+        assert any(ws["graph"] is not None for ws in llm._decode_ws.values())      # and the replayed graph was what ran
+        assert not torch.equal(ref_a, ref_b)
+    finally:
+        model.train()
+
+
 def test_vit_prefetch_on_a_side_stream_changes_nothing(model):
     """train_step(next_samples=...) issues the NEXT batch's frozen ViT forward on a side stream (its own split-K scratch)
     while this step runs, replayed from a hipGraph from the second batch of a shape on: four optimisation steps over four

@@ -12,6 +12,11 @@
 // j >= r (v) see the second draw of the same hash (seed with bit 63 set; common.h dropout_keep_pair).
 #include "common.h"
 
+// The 64-column border holds G = 64 / R2 GROUPS of R2 columns.  lora_down splits D into G ranges, one workgroup column per
+// range, and writes each range's partial product into its own group; the weight border repeats [B_q | B_v] G times, so the qkv
+// GEMM adds the partial products up by itself.  With 74 row blocks the kernel was a chain of load latencies on 74 CUs; 4
+// groups put 296 workgroups on the chip (lora_down 24.9 -> ~9 us per layer).
+#define LORA_BORDER 64
 #define LR_NT 256
 #define LR_NW 4
 #define LR_CH 64   // row chunks of the wgrad partial sums
@@ -39,11 +44,12 @@ __global__ __launch_bounds__(LD_NW * 64) void lora_down_kernel(const bf16_t* __r
   float4_t acc[NJ], accv[NJ];                      // acc: x under the q mask, accv: x under the v mask
 #pragma unroll
   for (int jj = 0; jj < NJ; ++jj) { acc[jj] = (float4_t){0.f, 0.f, 0.f, 0.f}; accv[jj] = (float4_t){0.f, 0.f, 0.f, 0.f}; }
-  const int steps = D / 32;
+  const int G = gridDim.y, grp = blockIdx.y;       // this workgroup's range of D: steps [gs0, gs0 + steps)
+  const int steps = D / 32 / G, gs0 = grp * steps;
   const int per = (steps + LD_NW - 1) / LD_NW;
-  const int s0 = wave * per, s1 = (s0 + per) < steps ? (s0 + per) : steps;
-  // 8 steps of loads in flight per lane: with 74 workgroups the kernel is a chain of load latencies, not bandwidth
-  constexpr int UN = 8;
+  const int s0 = gs0 + wave * per, s1 = (s0 + per) < (gs0 + steps) ? (s0 + per) : (gs0 + steps);
+  // several steps of loads in flight per lane: the kernel is a chain of load latencies, not bandwidth
+  constexpr int UN = 4;
   for (int st = s0; st < s1; st += UN) {
     short8_t xv[UN];
     float4_t a0[UN][NJ], a1[UN][NJ];
@@ -93,7 +99,7 @@ __global__ __launch_bounds__(LD_NW * 64) void lora_down_kernel(const bf16_t* __r
     float v = 0.f;
 #pragma unroll
     for (int w = 0; w < LD_NW; ++w) v += red[w][jj][rem];
-    if (m0 + row < M) out[(long)(m0 + row) * ldo + jj * 16 + j] = f2bf(scale * v);
+    if (m0 + row < M) out[(long)(m0 + row) * ldo + grp * R2 + jj * 16 + j] = f2bf(scale * v);
   }
 }
 
@@ -204,6 +210,8 @@ __global__ __launch_bounds__(LR_WG_NT) void lora_wgrad_partial_kernel(
       for (int j = 0; j < R2; ++j) {
         sg[j] = s * grow[j];
         st[j] = bf2f(brow[j]);
+#pragma unroll
+        for (int g = 1; g < LORA_BORDER / R2; ++g) st[j] += bf2f(brow[g * R2 + j]);   // the border's groups add up to s * t
       }
       if (live) {
 #pragma unroll
@@ -263,11 +271,14 @@ __global__ void lora_refresh_kernel(const float* __restrict__ Bq, const float* _
   if (i >= W * r) return;
   const int n = i / r, j = i - n * r;
   const bf16_t q = f2bf(Bq[i]), v = f2bf(Bv[i]);
-  ext[(long)n * ld_ext + D + j] = q;
-  ext[(long)(2 * W + n) * ld_ext + D + r + j] = v;
-  if (extT) {   // absent when the model was built without backward support (inference)
-    extT[(long)(D + j) * ld_extT + n] = q;
-    extT[(long)(D + r + j) * ld_extT + 2 * W + n] = v;
+  for (int g = 0; g < LORA_BORDER / (2 * r); ++g) {
+    const int c = D + g * 2 * r;
+    ext[(long)n * ld_ext + c + j] = q;
+    ext[(long)(2 * W + n) * ld_ext + c + r + j] = v;
+    if (extT) {   // absent when the model was built without backward support (inference)
+      extT[(long)(c + j) * ld_extT + n] = q;
+      extT[(long)(c + r + j) * ld_extT + 2 * W + n] = v;
+    }
   }
 }
 
@@ -279,11 +290,14 @@ __global__ void lora_refresh_all_kernel(const LoraRefreshEntry* __restrict__ tab
   const LoraRefreshEntry e = tab[blockIdx.y];
   const int n = i / r, j = i - n * r;
   const bf16_t q = f2bf(e.Bq[i]), v = f2bf(e.Bv[i]);
-  e.ext[(long)n * ld_ext + D + j] = q;
-  e.ext[(long)(2 * W + n) * ld_ext + D + r + j] = v;
-  if (e.extT) {
-    e.extT[(long)(D + j) * ld_extT + n] = q;
-    e.extT[(long)(D + r + j) * ld_extT + 2 * W + n] = v;
+  for (int g = 0; g < LORA_BORDER / (2 * r); ++g) {      // every group of the border carries [B_q | B_v]
+    const int c = D + g * 2 * r;
+    e.ext[(long)n * ld_ext + c + j] = q;
+    e.ext[(long)(2 * W + n) * ld_ext + c + r + j] = v;
+    if (e.extT) {
+      e.extT[(long)(c + j) * ld_extT + n] = q;
+      e.extT[(long)(c + r + j) * ld_extT + 2 * W + n] = v;
+    }
   }
 }
 
@@ -298,8 +312,10 @@ extern "C" int mh_lora_down(const void* x, long ldx, const float* A, void* borde
                             float s, float p, unsigned long long seed, hipStream_t stream) {
   if (M <= 0) return MH_OK;
   if (D % 4 || ldx % 4 || p < 0.f || p >= 1.f) return MH_ERR_ARG;
-  if (D % 32 || ldx % 8) return MH_ERR_ARG;
-  LORA_DISPATCH(R2_, hipLaunchKernelGGL(lora_down_kernel<R2>, dim3((M + 15) / 16), dim3(LD_NW * 64), 0, stream,
+  if (D % 32 || ldx % 8 || R2_ <= 0 || R2_ > LORA_BORDER) return MH_ERR_ARG;
+  int G = LORA_BORDER / R2_;                       // groups of the border; an unused group stays zero and contributes nothing
+  while (G > 1 && (D % (32 * G)) != 0) G >>= 1;
+  LORA_DISPATCH(R2_, hipLaunchKernelGGL(lora_down_kernel<R2>, dim3((M + 15) / 16, G), dim3(LD_NW * 64), 0, stream,
                                         (const bf16_t*)x, ldx, A, (bf16_t*)border, ldo, M, D, s, p, seed));
   MH_CHECK_LAUNCH();
   return MH_OK;

@@ -11,7 +11,8 @@ MI355X formulation -- the rank-r UP projection rides the main MFMA GEMMs as a K-
 so q/k/v are rounded to bf16 once and no extra pass over the [B*S, 12288] qkv buffer is needed; the skinny parts
 (lora-down, dx correction, dA/dB) are wavefront-primitive kernels in csrc/lora.hip that regenerate the dropout mask
 from (seed, index) instead of storing it -- one mask per wrapped Linear (peft gives q_proj and v_proj their own nn.Dropout).
-The 64-column border holds s*t_q (r) | s*t_v (r) | zeros.
+The 64-column border holds 64 / 2r groups of [s*t_q (r) | s*t_v (r)]: lora_down splits D over the groups (4x the workgroups of a
+latency-bound kernel) and the weight border repeats [B_q | B_v] per group, so the GEMM adds the partial products up.
 """
 from __future__ import annotations
 

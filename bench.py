@@ -296,6 +296,9 @@ def main():
     ap.add_argument("--no-prefetch-vit", action="store_true",
                     help="run the frozen ViT forward inline at the start of its own step instead of one step ahead on a side stream")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 line (BASELINE configs[1]) reported as config1_b1")
+    ap.add_argument("--host-inputs", action="store_true",
+                    help="inputs start in (pinned) host memory and every step uploads a fresh batch: the PCIe-inclusive rate "
+                         "(DESIGN.md; never the headline `value`, whose inputs are resident in HBM)")
     a = ap.parse_args()
 
     from myriad_amd import _lib
@@ -328,7 +331,21 @@ def main():
 
     prefetch = not a.no_prefetch_vit
 
+    host_batches = None
+    if a.host_inputs:
+        def host_batch(seed):
+            d = make_samples(a.batch, cfg["vocab"], seed, "cpu")
+            return {k: (v.pin_memory() if torch.is_tensor(v) and v.dtype.is_floating_point else v) for k, v in d.items()}
+        host_batches = [host_batch(1000 + rank * 100 + j) for j in range(4)]
+
     def step(i, smp=samples):
+        if host_batches is not None and smp is samples:
+            cur, nxt = dict(host_batches[i % 4]), dict(host_batches[(i + 1) % 4])     # fresh dicts: nothing cached across steps
+            if step.nxt is not None:
+                cur = step.nxt                                        # the batch whose ViT forward was issued one step ago
+            step.nxt = nxt
+            return model.train_step(cur, sched.step(0, i), 0.05, dp=dp if world > 1 else None, world=world, overlap=overlap,
+                                    next_samples=nxt if prefetch else None)
         # Input-pipeline lookahead of one batch (what a DataLoader with prefetch gives): every step issues the frozen ViT
         # forward of the NEXT step's batch on a side stream, where it fills the CUs this step leaves idle; one ViT forward
         # per step, as before.  N>1: the gradient all-reduce (RCCL, side stream) + AdamW of step i run while step i+1 waits
@@ -336,6 +353,7 @@ def main():
         return model.train_step(smp, sched.step(0, i), 0.05, dp=dp if world > 1 else None, world=world, overlap=overlap,
                                 next_samples=smp if prefetch else None)
 
+    step.nxt = None
     if prefetch:
         model.prepare_vit_graph(samples)      # the look-ahead's hipGraph is captured here, not inside a timed step (any --warmup)
     for i in range(a.warmup):

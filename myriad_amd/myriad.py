@@ -454,10 +454,18 @@ class MyriadHIP(nn.Module):
         return emb, attn, labels, img_slices
 
     def _image_of(self, samples):
-        image = samples["image"]
-        if "aug_image" in samples and self.training:
-            image = torch.cat([image, samples["aug_image"]])          # myriad.py:315-316
-        return image.to(self._dev, F32)
+        """[B(+B aug), 3, H, W] f32 on the device.  The uploaded tensor is remembered in the batch dict (keyed by the identity
+        of its host tensors): a look-ahead batch is touched twice -- its ViT forward one step early, the rest of its step
+        later -- and must cross PCIe once."""
+        src, aug = samples["image"], (samples.get("aug_image") if self.training else None)
+        cached = samples.get("_image_dev") if isinstance(samples, dict) else None
+        if cached is not None and cached[0] is src and cached[1] is aug:
+            return cached[2]
+        image = src if aug is None else torch.cat([src, aug])         # myriad.py:315-316
+        image = image.to(self._dev, F32, non_blocking=True)
+        if isinstance(samples, dict) and not src.is_cuda:
+            samples["_image_dev"] = (src, aug, image)
+        return image
 
     def attach_vision_expert(self, expert) -> None:
         """Optional in-model producer of the anomaly maps (`self.vision_expert` of the reference, myriad.py:83-90):

@@ -374,16 +374,21 @@ class RunnerBase:
         iters = int(run.get("iters_per_epoch", len(loader)))
         wd = float(run.get("weight_decay", 0.05))
         meters = {"lr": SmoothedValue(), "loss": SmoothedValue()}
+        pending = []
         samples = next(loader) if iters > 0 else None
         for i in range(iters):
             samples.update({"epoch": epoch, "num_iters_per_epoch": iters, "iters": i})      # base_task.py:217-223
             lr = sched.step(cur_epoch=epoch, cur_step=i)                                    # stepped BEFORE the forward (:229)
             nxt = next(loader) if i + 1 < iters else None                                   # one batch of lookahead: its frozen
             loss = model.train_step(samples, lr, wd, dp=self.dp, next_samples=nxt)          # ViT forward runs on a side stream
-            meters["loss"].update(float(loss))                                              # loss.item() per step (:276)
-            meters["lr"].update(lr)
-            if self.rank == 0 and (i % self.log_freq == 0 or i == iters - 1):
-                print(f"Train: data epoch: [{epoch}]  [{i}/{iters}]  lr: {lr:.6f}  loss: {meters['loss'].value:.4f}", flush=True)
+            pending.append(loss)                          # the reference reads loss.item() every step (:276), which stalls the
+            meters["lr"].update(lr)                       # launch thread behind the GPU; here the values are fetched at log points
+            if i % self.log_freq == 0 or i == iters - 1:
+                for t in pending:
+                    meters["loss"].update(float(t))
+                pending.clear()
+                if self.rank == 0:
+                    print(f"Train: data epoch: [{epoch}]  [{i}/{iters}]  lr: {lr:.6f}  loss: {meters['loss'].value:.4f}", flush=True)
             samples = nxt
         model.finish_update()
         if self.dp is not None:                                                             # logger.py:43-48 cross-rank average
@@ -401,6 +406,8 @@ class RunnerBase:
             if not self.evaluate_only:
                 stats = self.train_epoch(cur_epoch)
                 self.log_stats(stats, "train")
+                if self.dp is not None and getattr(self.dp, "mode", "") == "rs_ag":
+                    self.dp.gather_state(self.model.store)     # sharded AdamW: every rank owns 1/world of the moments (collective)
                 if self.rank == 0:                             # no validation split in the shipped recipes: save every epoch
                     lr = self.lr_scheduler.lr_at(cur_epoch, int(self.config.run_cfg.get("iters_per_epoch", 1)) - 1)
                     self.ckpt.save(self.model, cur_epoch, lr, float(self.config.run_cfg.get("weight_decay", 0.05)),

@@ -69,8 +69,15 @@ class EvaViTHIP:
     @torch.no_grad()
     def forward(self, image: torch.Tensor, rel_pos_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
         """image [B,3,H,W] f32 (device) -> [B, 1+np, D] f32."""
+        state = self.embed(image)
+        state = self.run_blocks(state, 0, len(self.blocks), rel_pos_bias)
+        return self.finish(state)
+
+    @torch.no_grad()
+    def embed(self, image: torch.Tensor):
+        """Patch embedding + cls / positional rows and the first block's LayerNorm: the state that run_blocks carries."""
         B = image.shape[0]
-        D, H, hd = self.D, self.H, self.hd
+        D = self.D
         patches = ops.patchify(image.contiguous(), self.P)               # [B*np, Kpad] bf16
         np_ = patches.shape[0] // B
         N = np_ + 1
@@ -79,14 +86,22 @@ class EvaViTHIP:
         for b in range(B):   # per image so the pos-embed rides the residual epilogue and rows land at x[b,1:]
             ops.gemm(patches[b * np_:(b + 1) * np_], self.patch_w, out=x[b, 1:], bias=self.patch_b,
                      residual=self.pos_patches)
+        h = x.view(B * N, D)
+        xn = ops.layernorm_fwd(h, self.blocks[0]["n1w"], self.blocks[0]["n1b"], self.eps)[0] if self.blocks else None
+        return (h, xn, B, N)
+
+    @torch.no_grad()
+    def run_blocks(self, state, lo: int, hi: int, rel_pos_bias: Optional[torch.Tensor] = None):
+        """Blocks lo .. hi-1 on a state from embed() / an earlier run_blocks (a forward may be issued in pieces)."""
+        h, xn, B, N = state
+        D, H, hd = self.D, self.H, self.hd
         M = B * N
-        h = x.view(M, D)
         scale = hd ** -0.5
         # each LayerNorm rides the split-K reduce of the GEMM that produces its input when that GEMM is split
         # (ops.gemm_residual_layernorm: fc2 -> next block's norm1, proj -> norm2); only block 0's norm1 is its own launch
         nb = len(self.blocks)
-        xn = ops.layernorm_fwd(h, self.blocks[0]["n1w"], self.blocks[0]["n1b"], self.eps)[0] if nb else None
-        for bi, blk in enumerate(self.blocks):
+        for bi in range(lo, hi):
+            blk = self.blocks[bi]
             qkv = ops.gemm(xn, blk["wqkv"], bias=blk["bqkv"]).view(B, N, 3 * D)
             o, _ = ops.attn_fwd(qkv[:, :, :D], qkv[:, :, D:2 * D], qkv[:, :, 2 * D:], H, hd, scale, bias=rel_pos_bias,
                                 need_lse=False)
@@ -97,4 +112,9 @@ class EvaViTHIP:
                 h, xn = ops.gemm_residual_layernorm(a, blk["w2"], blk["b2"], h, nxt["n1w"], nxt["n1b"], self.eps)
             else:
                 h = ops.gemm(a, blk["w2"], bias=blk["b2"], residual=h, out_dtype=F32)
-        return h.view(B, N, D)
+        return (h, xn, B, N)
+
+    @staticmethod
+    def finish(state) -> torch.Tensor:
+        h, _, B, N = state
+        return h.view(B, N, -1)

@@ -258,7 +258,9 @@ class MyriadHIP(nn.Module):
             self.llama.attach_lora(self.lora)
         self._pending_update = None
         self._vit_stream, self._vit_prefetched = None, None
-        self._vit_graphs, self._vit_seen = {}, {}
+        self._vit_graphs, self._vit_seen, self._vit_rest = {}, {}, None
+        # blocks in the look-ahead's first piece (of 39): measured 39 -> 50.9, 30 -> 49.6, 24 -> 49.1, 20 -> 49.1, 12 -> 50.8, 0 -> 52.3 ms
+        self._vit_split = int(os.environ.get("MYRIAD_VIT_SPLIT", "22"))
         self._vit_graph_on = os.environ.get("MYRIAD_VIT_GRAPH", "1") != "0"
         self._leaf_aside = os.environ.get("MYRIAD_LEAF_STREAM", "1") != "0"
         self._anchor = torch.zeros((), device=self._dev, requires_grad=True)
@@ -543,6 +545,7 @@ class MyriadHIP(nn.Module):
         self.store.mark_used(used)
         self._bwd_gscale, self._bwd_prev = float(gscale), prev
         demb = self.llama.backward(defer_lora_join=True)              # [B,S,Dl] f32; LoRA wgrads run on a side stream
+        self._prefetch_vit_rest()                                     # the look-ahead's second piece: beside the light tail of the step
         B, nq = c["B"], c["nq"]
         (c0, n0) = c["img_slices"][0]
         dimg = torch.empty((B, nq, self.Dl), dtype=F32, device=self._dev)
@@ -611,14 +614,20 @@ class MyriadHIP(nn.Module):
         return ops.side_stream(self._dev, name)
 
     def prefetch_vit(self, samples) -> None:
-        """Launch the frozen ViT forward of a LATER step on a side stream, so that it fills the CUs the current step leaves
-        idle (partial tile rounds, launch gaps, latency-bound small kernels).  The result is picked up by the train_step()
-        that receives the same `samples` object.  Its split-K GEMMs use their own scratch (mh_set_stream_workspace).
-        From the second batch of a given size on, the ~290 launches are replayed from a hipGraph captured on that stream
-        (fixed shapes, frozen weights, no host-side arguments): enqueueing them costs the launch thread ~0.1 ms instead of
+        """Launch the frozen ViT forward of a LATER step on a side stream.  The result is picked up by the train_step() that
+        receives the same `samples` object.  Its split-K GEMMs use their own scratch (mh_set_stream_workspace).
+
+        The forward is issued in two pieces.  Its GEMMs are work the chip has to do -- run beside the LLaMA part they cost
+        almost their own duration -- but the step has two phases in which the main stream leaves most CUs idle (chains of
+        5-30 us launches): the adaptor / Q-Former forward at its start, and the Q-Former / adaptor backward + AdamW at its
+        end.  The first `MYRIAD_VIT_SPLIT` blocks are launched here, at the start of the step; the rest by
+        _prefetch_vit_rest(), which backward() calls once the LLaMA backward is enqueued.
+        From the second batch of a given size on, both pieces are replayed from hipGraphs captured on that stream (fixed
+        shapes, frozen weights, no host-side arguments): enqueueing ~290 launches costs the launch thread ~0.2 ms instead of
         ~2.8 ms during which the main stream had nothing to run (MYRIAD_VIT_GRAPH=0 disables)."""
         if self._vit_stream is None:
             self._vit_stream = self._side_stream("vit")
+        self._prefetch_vit_rest()                        # a look-ahead that was never consumed / finished: finish it first
         main = torch.cuda.current_stream()
         image = self._image_of(samples)
         key = tuple(image.shape)
@@ -626,21 +635,38 @@ class MyriadHIP(nn.Module):
         if graph is None and self._vit_graph_on and self._vit_seen.get(key, 0) >= 1 and image.dtype == F32:
             graph = self._capture_vit(image)
         self._vit_seen[key] = self._vit_seen.get(key, 0) + 1
+        nb = len(self.visual_encoder.blocks)
+        split = min(max(self._vit_split, 0), nb)
         self._vit_stream.wait_stream(main)               # inputs uploaded / buffers freed on the main stream so far
         with torch.cuda.stream(self._vit_stream), torch.no_grad():
             if graph is not None:
-                g, static_in, static_out = graph
-                static_in.copy_(image)
-                g.replay()
-                out = static_out.clone()                  # the next replay overwrites static_out while this step's backward reads `out`
+                graph["in"].copy_(image)
+                graph["a"].replay()
+                state = None
             else:
-                out = self.visual_encoder.forward(image)
+                state = self.visual_encoder.run_blocks(self.visual_encoder.embed(image), 0, split)
+        self._vit_rest = (samples, graph, state, split)
+
+    def _prefetch_vit_rest(self) -> None:
+        """Second piece of a look-ahead ViT forward (see prefetch_vit): ordered behind everything the main stream has queued."""
+        if self._vit_rest is None:
+            return
+        samples, graph, state, split = self._vit_rest
+        self._vit_rest = None
+        self._vit_stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self._vit_stream), torch.no_grad():
+            if graph is not None:
+                graph["b"].replay()
+                out = graph["out"].clone()               # the next replay overwrites it while this step's backward reads `out`
+            else:
+                ve = self.visual_encoder
+                out = ve.finish(ve.run_blocks(state, split, len(ve.blocks)))
             ev = torch.cuda.Event()
             ev.record()
         self._vit_prefetched = (samples, out, ev)
 
     def prepare_vit_graph(self, samples) -> None:
-        """Capture the look-ahead graph for this batch's image shape now (one eager pass + the capture: ~0.1 s), so that no
+        """Capture the look-ahead graphs for this batch's image shape now (one eager pass + the capture: ~0.1 s), so that no
         later train_step pays for it.  Without this call the capture happens at the second look-ahead of a shape."""
         image = self._image_of(samples)
         key = tuple(image.shape)
@@ -655,20 +681,28 @@ class MyriadHIP(nn.Module):
         self._capture_vit(image)
 
     def _capture_vit(self, image):
-        """Capture visual_encoder.forward at this input shape into a hipGraph on the ViT side stream (whose split-K scratch the
-        captured launches keep using on replay).  Called after one eager pass at the shape, so no kernel does first-call set-up
-        inside the capture."""
+        """Capture the two pieces of visual_encoder.forward at this input shape into hipGraphs on the ViT side stream (whose
+        split-K scratch the captured launches keep using on replay).  Called after one eager pass at the shape, so no kernel
+        does first-call set-up inside the capture.  The pieces share one memory pool: piece b reads piece a's state."""
         torch.cuda.synchronize()
+        ve = self.visual_encoder
+        split = min(max(self._vit_split, 0), len(ve.blocks))
         static_in = torch.empty_like(image).contiguous()
         static_in.copy_(image)
-        g = torch.cuda.CUDAGraph()
+        ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread_local: a data-parallel run has RCCL's watchdog thread polling events while this thread captures
-        with torch.no_grad(), torch.cuda.graph(g, stream=self._vit_stream, capture_error_mode="thread_local"):
-            static_out = self.visual_encoder.forward(static_in)
-        self._vit_graphs[tuple(image.shape)] = (g, static_in, static_out)
-        return self._vit_graphs[tuple(image.shape)]
+        with torch.no_grad(), torch.cuda.graph(ga, stream=self._vit_stream, capture_error_mode="thread_local"):
+            state = ve.run_blocks(ve.embed(static_in), 0, split)
+        with torch.no_grad(), torch.cuda.graph(gb, pool=ga.pool(), stream=self._vit_stream, capture_error_mode="thread_local"):
+            static_out = ve.finish(ve.run_blocks(state, split, len(ve.blocks)))
+        g = dict(a=ga, b=gb, out=static_out, state=state)
+        g["in"] = static_in
+        self._vit_graphs[tuple(image.shape)] = g
+        return g
 
     def _take_prefetched_vit(self, samples):
+        if self._vit_rest is not None and self._vit_rest[0] is samples:
+            self._prefetch_vit_rest()                    # its second piece was never issued (no backward in between)
         if self._vit_prefetched is None or self._vit_prefetched[0] is not samples:
             return None
         _, out, ev = self._vit_prefetched

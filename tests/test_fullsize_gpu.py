@@ -160,4 +160,4 @@ def test_vit_prefetch_on_a_side_stream_changes_nothing(model):
         assert not torch.equal(a[1], keep[0])                    # and the steps did move the parameters
     finally:
         st.flat_p.copy_(keep[0]); st.flat_m.copy_(keep[1]); st.flat_v.copy_(keep[2]); st.step = keep[3]; st.steps_dev.copy_(keep[4])
-        model._vit_prefetched = None
+        model._vit_prefetched, model._vit_rest = None, None

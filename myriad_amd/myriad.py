@@ -656,7 +656,8 @@ class MyriadHIP(nn.Module):
         self._vit_stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self._vit_stream), torch.no_grad():
             if graph is not None:
-                graph["b"].replay()
+                if graph["b"] is not None:
+                    graph["b"].replay()
                 out = graph["out"].clone()               # the next replay overwrites it while this step's backward reads `out`
             else:
                 ve = self.visual_encoder
@@ -693,8 +694,11 @@ class MyriadHIP(nn.Module):
         # thread_local: a data-parallel run has RCCL's watchdog thread polling events while this thread captures
         with torch.no_grad(), torch.cuda.graph(ga, stream=self._vit_stream, capture_error_mode="thread_local"):
             state = ve.run_blocks(ve.embed(static_in), 0, split)
-        with torch.no_grad(), torch.cuda.graph(gb, pool=ga.pool(), stream=self._vit_stream, capture_error_mode="thread_local"):
-            static_out = ve.finish(ve.run_blocks(state, split, len(ve.blocks)))
+        if split < len(ve.blocks):
+            with torch.no_grad(), torch.cuda.graph(gb, pool=ga.pool(), stream=self._vit_stream, capture_error_mode="thread_local"):
+                static_out = ve.finish(ve.run_blocks(state, split, len(ve.blocks)))
+        else:
+            gb, static_out = None, ve.finish(state)          # a shallow encoder: everything is in the first piece
         g = dict(a=ga, b=gb, out=static_out, state=state)
         g["in"] = static_in
         self._vit_graphs[tuple(image.shape)] = g

@@ -184,49 +184,57 @@ __global__ __launch_bounds__(LR_WG_NT) void lora_wgrad_partial_kernel(
   for (int j = 0; j < r; ++j)
 #pragma unroll
     for (int e = 0; e < 4; ++e) { bq[j][e] = 0.f; bv[j][e] = 0.f; }
-  // three token rows per trip so that their loads overlap (the loop was one exposed load latency per row)
+  // The 2*R2 per-row scalars (s * d(border), border summed over its groups) are staged through LDS for 32 rows at a time: as
+  // wave-uniform global reads inside the row loop they were one exposed scalar-load latency per row (19 per workgroup).
+  // Three token rows per trip so that their vector loads overlap.
+  __shared__ float s_sg[32][R2], s_st[32][R2];
   constexpr int RU = 3;
-  for (int mb = m0; mb < m1; mb += RU) {
-    short4_t xv[RU], qv[RU], vv[RU];
+  for (int mb0 = m0; mb0 < m1; mb0 += 32) {
+    const int nrow = (m1 - mb0) < 32 ? (m1 - mb0) : 32;
+    __syncthreads();
+    for (int i = threadIdx.x; i < nrow * R2; i += LR_WG_NT) {
+      const int rr = i / R2, j = i - rr * R2;
+      const long m = mb0 + rr;
+      s_sg[rr][j] = s * dx_ext[m * ldg + D + j];
+      float t = 0.f;
 #pragma unroll
-    for (int u = 0; u < RU; ++u) {
-      const int m = (mb + u) < m1 ? (mb + u) : (m1 - 1);
-      xv[u] = qv[u] = vv[u] = (short4_t){0, 0, 0, 0};
-      if (live) {
-        xv[u] = *reinterpret_cast<const short4_t*>(x + (long)m * ldx + d);
-        qv[u] = *reinterpret_cast<const short4_t*>(dq + (long)m * ldq + d);
-        vv[u] = *reinterpret_cast<const short4_t*>(dv + (long)m * ldq + d);
-      }
+      for (int g = 0; g < LORA_BORDER / R2; ++g) t += bf2f(border[m * ldb + g * R2 + j]);   // the border's groups add up to s * t
+      s_st[rr][j] = t;
     }
+    __syncthreads();
+    for (int mb = mb0; mb < mb0 + nrow; mb += RU) {
+      short4_t xv[RU], qv[RU], vv[RU];
 #pragma unroll
-    for (int u = 0; u < RU; ++u) {
-      const int m = mb + u;
-      if (m >= m1) break;
-      // the 2*R2 per-row scalars are wave-uniform addresses: the compiler turns them into scalar (s_load) reads
-      float sg[R2], st[R2];
-      const float* grow = dx_ext + (long)m * ldg + D;
-      const bf16_t* brow = border + (long)m * ldb;
-#pragma unroll
-      for (int j = 0; j < R2; ++j) {
-        sg[j] = s * grow[j];
-        st[j] = bf2f(brow[j]);
-#pragma unroll
-        for (int g = 1; g < LORA_BORDER / R2; ++g) st[j] += bf2f(brow[g * R2 + j]);   // the border's groups add up to s * t
+      for (int u = 0; u < RU; ++u) {
+        const int m = (mb + u) < m1 ? (mb + u) : (m1 - 1);
+        xv[u] = qv[u] = vv[u] = (short4_t){0, 0, 0, 0};
+        if (live) {
+          xv[u] = *reinterpret_cast<const short4_t*>(x + (long)m * ldx + d);
+          qv[u] = *reinterpret_cast<const short4_t*>(dq + (long)m * ldq + d);
+          vv[u] = *reinterpret_cast<const short4_t*>(dv + (long)m * ldq + d);
+        }
       }
-      if (live) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float kq, kv;
-          dropout_keep_pair(seed, (unsigned long long)((long)m * D + d + e), p, ik, kq, kv);
-          const float x0 = bf2f((bf16_t)xv[u][e]);
-          const float xd = x0 * kq, xw = x0 * kv;
-          const float gq = bf2f((bf16_t)qv[u][e]), gv = bf2f((bf16_t)vv[u][e]);
+      for (int u = 0; u < RU; ++u) {
+        const int m = mb + u;
+        if (m >= mb0 + nrow) break;
+        const float* sg = s_sg[m - mb0];
+        const float* st = s_st[m - mb0];
+        if (live) {
 #pragma unroll
-          for (int j = 0; j < r; ++j) { a[j][e] += sg[j] * xd; a[r + j][e] += sg[r + j] * xw; }
+          for (int e = 0; e < 4; ++e) {
+            float kq, kv;
+            dropout_keep_pair(seed, (unsigned long long)((long)m * D + d + e), p, ik, kq, kv);
+            const float x0 = bf2f((bf16_t)xv[u][e]);
+            const float xd = x0 * kq, xw = x0 * kv;
+            const float gq = bf2f((bf16_t)qv[u][e]), gv = bf2f((bf16_t)vv[u][e]);
 #pragma unroll
-          for (int j = 0; j < r; ++j) {
-            bq[j][e] += gq * st[j];
-            bv[j][e] += gv * st[r + j];
+            for (int j = 0; j < r; ++j) { a[j][e] += sg[j] * xd; a[r + j][e] += sg[r + j] * xw; }
+#pragma unroll
+            for (int j = 0; j < r; ++j) {
+              bq[j][e] += gq * st[j];
+              bv[j][e] += gv * st[r + j];
+            }
           }
         }
       }

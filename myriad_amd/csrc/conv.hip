@@ -50,7 +50,7 @@ __global__ void im2col_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__
 extern "C" int mh_im2col_nhwc(const void* x, void* col, int B, int H, int W, int C, int kh, int kw, int pad, int Kpad,
                               hipStream_t stream) {
   const int OH = H + 2 * pad - kh + 1, OW = W + 2 * pad - kw + 1, K = kh * kw * C;
-  if (Kpad % 4 || Kpad < K + 1 || OH <= 0 || OW <= 0) return MH_ERR_ARG;
+  if (Kpad % 4 || Kpad < K || OH <= 0 || OW <= 0) return MH_ERR_ARG;   // Kpad == K: no bias (ones) column
   const long total = (long)B * OH * OW * (Kpad / 4);
   hipLaunchKernelGGL(im2col_kernel, dim3(cv_grid(total)), dim3(CV_NT), 0, stream, (const bf16_t*)x, (bf16_t*)col, B, H,
                      W, C, kh, kw, pad, OH, OW, K, Kpad);

@@ -671,10 +671,12 @@ def decode_record(nxt, margin, pmax, rec, next_ids, step_dev):
 
 
 # --------------------------------------------------------------------------- conv stack pieces
-def im2col(x_nhwc: torch.Tensor, kh: int, kw: int, pad: int):
+def im2col(x_nhwc: torch.Tensor, kh: int, kw: int, pad: int, bias_col: bool = True):
+    """[B*OH*OW, Kpad] bf16 patches, (ky, kx, c) order; with bias_col a column of ones follows the K patch columns (the bias
+    then rides the GEMM as one more weight column)."""
     B, H, W, C = x_nhwc.shape
     OH, OW = H + 2 * pad - kh + 1, W + 2 * pad - kw + 1
-    Kpad = round_up(kh * kw * C + 1, 64)
+    Kpad = round_up(kh * kw * C + (1 if bias_col else 0), 64)
     col = torch.empty((B * OH * OW, Kpad), dtype=BF16, device=x_nhwc.device)
     _lib.check(_L().mh_im2col_nhwc(_p(x_nhwc), _p(col), B, H, W, C, kh, kw, pad, Kpad, _s()), "mh_im2col_nhwc")
     return col

@@ -295,3 +295,30 @@ def test_train_loop_looks_one_batch_ahead():
     train_loop(m2, data_iter, 3, sched, lookahead=False)
     assert drawn == [0, 1, 2] and [(c[0], c[1]) for c in m2.calls] == [(0, None), (1, None), (2, None)]
     assert train_loop(Recorder(), data_iter, 0, sched) == []
+
+
+REF = "/root/reference"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="the reference checkout exists in the build container only")
+@pytest.mark.parametrize("rel", ["train_configs/loraadapter_simple_myriad_finetune.yaml", "train_configs/minigpt4_stage2_finetune.yaml",
+                                 "eval_configs/myriad.yaml"])
+def test_config_reads_the_reference_yaml_files_unchanged(rel):
+    """`Config` (the OmegaConf-free counterpart of minigpt4/common/config.py:16-51) on the reference's own YAML files: model
+    defaults <- file <- --options, scientific-notation floats as floats, every section reachable by attribute and key."""
+    import argparse
+    from myriad_amd.config import Config
+    path = os.path.join(REF, rel)
+    cfg = Config(argparse.Namespace(cfg_path=path, options=["run.max_epoch=3", "model.max_txt_len=77"]))
+    m, r = cfg.model_cfg, cfg.run_cfg
+    assert m.arch in ("myriad", "mini_gpt4") and m["arch"] == m.arch
+    assert m.max_txt_len == 77                                       # --options wins over the file
+    assert m.get("llama_model") and m.get("image_size") == 224       # keys that only the model's default YAML carries
+    assert m.get("freeze_vit", True) is True
+    if "train_configs" in rel:
+        assert r.max_epoch == 3 and isinstance(r.init_lr, float) and 0 < r.init_lr < 1e-3      # written as 1e-4 / 3e-5 in the files
+        assert isinstance(r.warmup_lr, float) and r.weight_decay == 0.05 and r.lr_sched == "linear_warmup_cosine_lr"
+        assert r.seed == 42 and r.distributed is True and r.resume_ckpt_path is None
+    assert len(cfg.datasets_cfg) >= 1
+    d = cfg.to_dict()
+    assert set(d) >= {"model", "run", "datasets"}

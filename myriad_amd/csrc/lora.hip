@@ -202,18 +202,26 @@ __global__ __launch_bounds__(LR_WG_NT) void lora_wgrad_partial_kernel(
       s_st[rr][j] = t;
     }
     __syncthreads();
-    for (int mb = mb0; mb < mb0 + nrow; mb += RU) {
-      short4_t xv[RU], qv[RU], vv[RU];
+    // software pipeline over trips of RU rows: the loads of trip t+1 are in flight while trip t is multiplied
+    short4_t xn[RU], qn[RU], vn[RU];
+    auto load_trip = [&](int mb) {
 #pragma unroll
       for (int u = 0; u < RU; ++u) {
         const int m = (mb + u) < m1 ? (mb + u) : (m1 - 1);
-        xv[u] = qv[u] = vv[u] = (short4_t){0, 0, 0, 0};
+        xn[u] = qn[u] = vn[u] = (short4_t){0, 0, 0, 0};
         if (live) {
-          xv[u] = *reinterpret_cast<const short4_t*>(x + (long)m * ldx + d);
-          qv[u] = *reinterpret_cast<const short4_t*>(dq + (long)m * ldq + d);
-          vv[u] = *reinterpret_cast<const short4_t*>(dv + (long)m * ldq + d);
+          xn[u] = *reinterpret_cast<const short4_t*>(x + (long)m * ldx + d);
+          qn[u] = *reinterpret_cast<const short4_t*>(dq + (long)m * ldq + d);
+          vn[u] = *reinterpret_cast<const short4_t*>(dv + (long)m * ldq + d);
         }
       }
+    };
+    load_trip(mb0);
+    for (int mb = mb0; mb < mb0 + nrow; mb += RU) {
+      short4_t xv[RU], qv[RU], vv[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) { xv[u] = xn[u]; qv[u] = qn[u]; vv[u] = vn[u]; }
+      if (mb + RU < mb0 + nrow) load_trip(mb + RU);
 #pragma unroll
       for (int u = 0; u < RU; ++u) {
         const int m = mb + u;

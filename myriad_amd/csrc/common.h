@@ -70,6 +70,16 @@ __device__ __forceinline__ void dropout_keep_pair(unsigned long long seed, unsig
   k1 = (float)(dropout_hash2(h) >> 8) * (1.0f / 16777216.0f) >= p ? inv_keep : 0.f;
 }
 
+// Split-K partial slabs are fp32, or bf16 when the 256x256 kernel produced them (gemm.hip run_splitk): four consecutive
+// elements at element index idx of a slab base, as fp32.
+__device__ __forceinline__ float4_t slab_load4(const void* base, long idx, int slab_bf16) {
+  if (slab_bf16) {
+    const short4_t h = *reinterpret_cast<const short4_t*>(reinterpret_cast<const bf16_t*>(base) + idx);
+    return (float4_t){bf2f((bf16_t)h[0]), bf2f((bf16_t)h[1]), bf2f((bf16_t)h[2]), bf2f((bf16_t)h[3])};
+  }
+  return *reinterpret_cast<const float4_t*>(reinterpret_cast<const float*>(base) + idx);
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);

@@ -303,18 +303,18 @@ static int dispatch(const GemmArgs& g, hipStream_t stream) {
 // Used (a) for skinny wgrad outputs with a huge reduction and (b) automatically for shapes whose 128x128 tile
 // count leaves the 256 CUs under-filled (N = 4096 dgrad / down-proj at M ~ 1.2k: 320 tiles; ViT N = 1408: 187 tiles):
 // measured cold-weight gains +9..25 % including the reduce pass (profiles/r01_gemm_splitk.md).
-__global__ void splitk_reduce_kernel(const float* __restrict__ ws, void* __restrict__ outv, const float* __restrict__ bias,
+__global__ void splitk_reduce_kernel(const void* __restrict__ ws, void* __restrict__ outv, const float* __restrict__ bias,
                                      const float* res, int M, int N, int ldc, int ldr, int splits, int flags,
-                                     float alpha) {
+                                     float alpha, int sbf) {
   const long total4 = (long)M * N / 4;
   const long slab = (long)M * N;
   const bool out_f32 = flags & MH_GEMM_OUT_F32;
   const bool do_gelu = flags & MH_GEMM_GELU;
   for (long i4 = blockIdx.x * (long)blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
     const long i = i4 * 4;
-    float4_t s = *reinterpret_cast<const float4_t*>(ws + i);
+    float4_t s = slab_load4(ws, i, sbf);
     for (int k = 1; k < splits; ++k) {
-      const float4_t p = *reinterpret_cast<const float4_t*>(ws + (long)k * slab + i);
+      const float4_t p = slab_load4(ws, (long)k * slab + i, sbf);
       s[0] += p[0]; s[1] += p[1]; s[2] += p[2]; s[3] += p[3];
     }
     const long m = i / N;
@@ -351,20 +351,20 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, void* __restr
 // NORM 0: RMSNorm (y = w * h * rsqrt(mean(h^2) + eps));  NORM 1: LayerNorm (y = (h - mean) * rsqrt(var + eps) * w + nb,
 // eva_vit.py:175-179 / ImageBind transformer.py:160-163) -- each written exactly as norm.hip writes it.
 template <int NORM>
-__global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __restrict__ ws, const float* __restrict__ bias,
+__global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const void* __restrict__ ws, const float* __restrict__ bias,
                                                                  const float* res, float* hout, const float* __restrict__ w,
                                                                  const float* __restrict__ nb, bf16_t* __restrict__ y, int N,
                                                                  long ldr, long ldh, long ldy, long slab, int splits,
-                                                                 float eps) {
+                                                                 float eps, int sbf) {
   __shared__ float red[4];
   const long row = blockIdx.x;
   float4_t hv[8];                                   // N <= 8192
   float acc1 = 0.f;                                 // sum of squares (RMS) or plain sum (LayerNorm)
   int c = 0;
   for (int i = threadIdx.x * 4; i < N; i += 1024, ++c) {
-    float4_t sacc = *reinterpret_cast<const float4_t*>(ws + row * N + i);
+    float4_t sacc = slab_load4(ws, row * N + i, sbf);
     for (int k = 1; k < splits; ++k) {
-      const float4_t p = *reinterpret_cast<const float4_t*>(ws + (long)k * slab + row * N + i);
+      const float4_t p = slab_load4(ws, (long)k * slab + row * N + i, sbf);
       sacc[0] += p[0]; sacc[1] += p[1]; sacc[2] += p[2]; sacc[3] += p[3];
     }
     float v[4] = {sacc[0] * 1.0f, sacc[1] * 1.0f, sacc[2] * 1.0f, sacc[3] * 1.0f};
@@ -413,16 +413,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const float* __
   }
 }
 
-static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t stream, bool reduce = true) {
+// Slabs of the 256x256 kernel are bf16 (MYRIAD_SLAB_BF16=0: fp32): these are the K <= 22016 forward / dgrad products of the
+// LLaMA and ViT Linears, whose results are rounded to bf16 (or added to the fp32 residual stream) anyway; the partial sums cost
+// 2 x 4 B per output element per split in fp32 -- 9 GB per step at batch 8.  The 128x128 kernel's slabs (weight gradients: long
+// cancelling reductions over tokens) stay fp32.  *slab_bf16 tells the caller which it got.
+static int g_slab_bf16 = -1;
+extern "C" void mhdbg_set_slab_bf16(int on) { g_slab_bf16 = on ? 1 : 0; }   // debug hook (tests), not part of the ABI
+
+static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t stream, bool reduce = true, int* slab_bf16 = nullptr) {
+  if (g_slab_bf16 < 0) { const char* e = getenv("MYRIAD_SLAB_BF16"); g_slab_bf16 = (e && e[0] == '0') ? 0 : 1; }
   const int nt = g0.K / 64;
   if (splits > nt) splits = nt;
   const int tps = (nt + splits - 1) / splits;
   splits = (nt + tps - 1) / tps;
+  const bool big = ((g0.flags >> MH_GEMM_VARIANT_SHIFT) & 15) == 12;
+  const int sbf = (big && g_slab_bf16 && (g0.N % 8) == 0) ? 1 : 0;
+  if (slab_bf16) *slab_bf16 = sbf;
   GemmArgs g = g0;
   g.C = (void*)ws; g.ldc = g0.N; g.bias = nullptr; g.residual = nullptr; g.ldr = 0;
-  g.flags = MH_GEMM_OUT_F32; g.alpha = 1.0f; g.splits = splits; g.tps = tps; g.split_stride = (long)g0.M * g0.N;
+  g.flags = sbf ? 0 : MH_GEMM_OUT_F32; g.alpha = 1.0f; g.splits = splits; g.tps = tps; g.split_stride = (long)g0.M * g0.N;
   int rc;
-  if (((g0.flags >> MH_GEMM_VARIANT_SHIFT) & 15) == 12)
+  if (big)
     rc = mh_launch_gemm_256(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, nullptr, nullptr, 0, g.flags, 1.0f,
                             g.splits, g.tps, g.split_stride, stream);
   else
@@ -431,8 +442,8 @@ static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t str
   if (!reduce) return MH_OK;                        // the caller consumes the slabs itself
   long gsz = ((long)g0.M * g0.N / 4 + 255) / 256;
   if (gsz > 4096) gsz = 4096;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)gsz), dim3(256), 0, stream, ws, g0.C, g0.bias, g0.residual, g0.M,
-                     g0.N, g0.ldc, g0.ldr, splits, g0.flags, g0.alpha);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)gsz), dim3(256), 0, stream, (const void*)ws, g0.C, g0.bias, g0.residual,
+                     g0.M, g0.N, g0.ldc, g0.ldr, splits, g0.flags, g0.alpha, sbf);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
@@ -598,14 +609,15 @@ static int gemm_residual_norm(int norm, const void* A, int lda, const void* B, i
     const int tps = (nt + sp - 1) / sp;
     sp = (nt + tps - 1) / tps;
     float* wsp = ws_for(stream);
-    int rc = run_splitk(g, splits, wsp, stream, /*reduce=*/false);
+    int sbf = 0;
+    int rc = run_splitk(g, splits, wsp, stream, /*reduce=*/false, &sbf);
     if (rc) return rc;
     if (norm == 0)
-      hipLaunchKernelGGL(splitk_reduce_norm_kernel<0>, dim3(M), dim3(256), 0, stream, wsp, bias, residual, H, norm_w, norm_b,
-                         (bf16_t*)Y, N, (long)ldr, (long)ldh, ldy, (long)M * N, sp, eps);
+      hipLaunchKernelGGL(splitk_reduce_norm_kernel<0>, dim3(M), dim3(256), 0, stream, (const void*)wsp, bias, residual, H, norm_w,
+                         norm_b, (bf16_t*)Y, N, (long)ldr, (long)ldh, ldy, (long)M * N, sp, eps, sbf);
     else
-      hipLaunchKernelGGL(splitk_reduce_norm_kernel<1>, dim3(M), dim3(256), 0, stream, wsp, bias, residual, H, norm_w, norm_b,
-                         (bf16_t*)Y, N, (long)ldr, (long)ldh, ldy, (long)M * N, sp, eps);
+      hipLaunchKernelGGL(splitk_reduce_norm_kernel<1>, dim3(M), dim3(256), 0, stream, (const void*)wsp, bias, residual, H, norm_w, norm_b,
+                         (bf16_t*)Y, N, (long)ldr, (long)ldh, ldy, (long)M * N, sp, eps, sbf);
     MH_CHECK_LAUNCH();
     return MH_OK;
   }
@@ -628,8 +640,8 @@ extern "C" int mh_gemm_residual_layernorm(const void* A, int lda, const void* B,
   return gemm_residual_norm(1, A, lda, B, ldb, H, ldh, bias, residual, ldr, norm_w, norm_b, eps, Y, N, M, N, K, stream);
 }
 
-int mh_launch_rmsnorm_bwd(const float* dy, int nslab, long slab, long ldy, const float* x, const float* w, const float* dres,
-                          float* dx, void* dx_bf16, int M, int D, float eps, hipStream_t stream);
+int mh_launch_rmsnorm_bwd(const void* dy, int slab_bf16, int nslab, long slab, long ldy, const float* x, const float* w,
+                          const float* dres, float* dx, void* dx_bf16, int M, int D, float eps, hipStream_t stream);
 
 // dY[M,N] = A.B^T (a dgrad GEMM), then the RMSNorm backward that consumes it (modeling_llama.py:66-74 under autograd):
 // dx = rmsnorm_bwd(dY, x, w) + dres.  When the policy splits K the norm kernel sums the partial slabs itself; otherwise dY
@@ -650,17 +662,18 @@ extern "C" int mh_gemm_rmsnorm_bwd(const void* A, int lda, const void* B, int ld
     const int tps = (nt + sp - 1) / sp;
     sp = (nt + tps - 1) / tps;
     float* wsp = ws_for(stream);
-    const int rc = run_splitk(g, splits, wsp, stream, /*reduce=*/false);
+    int sbf = 0;
+    const int rc = run_splitk(g, splits, wsp, stream, /*reduce=*/false, &sbf);
     if (rc) return rc;
-    return mh_launch_rmsnorm_bwd(wsp, sp, (long)M * N, N, x, w, dres, dx, dx_bf16, M, N, eps, stream);
+    return mh_launch_rmsnorm_bwd(wsp, sbf, sp, (long)M * N, N, x, w, dres, dx, dx_bf16, M, N, eps, stream);
   }
   const int rc = mh_gemm_bf16_nt(A, lda, B, ldb, dy_buf, N, M, N, K, nullptr, nullptr, 0, MH_GEMM_OUT_F32, 1.0f, stream);
   if (rc) return rc;
-  return mh_launch_rmsnorm_bwd(dy_buf, 1, 0, N, x, w, dres, dx, dx_bf16, M, N, eps, stream);
+  return mh_launch_rmsnorm_bwd(dy_buf, 0, 1, 0, N, x, w, dres, dx, dx_bf16, M, N, eps, stream);
 }
 
-int mh_launch_lora_dx(const float* dx_ext, long ld, int nslab, long slab, const float* A, float* out, float* border_out, int M,
-                      int D, int R2_, float s, float p, unsigned long long seed, hipStream_t stream);
+int mh_launch_lora_dx(const void* dx_ext, int slab_bf16, long ld, int nslab, long slab, const float* A, float* out, float* border_out,
+                      int M, int D, int R2_, float s, float p, unsigned long long seed, hipStream_t stream);
 
 // The qkv dgrad with the LoRA border, [M, D + 64] = dqkv . [W_qkv | B_ext] (myriad_amd/lora.py), followed by the LoRA dx
 // correction that reads it (lora.hip).  When the policy splits K the correction kernel sums the partial slabs itself (same
@@ -684,14 +697,15 @@ extern "C" int mh_gemm_lora_dx(const void* A, int lda, const void* Bw, int ldb, 
     const int tps = (nt + sp - 1) / sp;
     sp = (nt + tps - 1) / tps;
     float* wsp = ws_for(stream);
-    const int rc = run_splitk(g, splits, wsp, stream, /*reduce=*/false);
+    int sbf = 0;
+    const int rc = run_splitk(g, splits, wsp, stream, /*reduce=*/false, &sbf);
     if (rc) return rc;
-    return mh_launch_lora_dx(wsp, N, sp, (long)M * N, loraA, dxn, border_out, M, D, R2, s, p, seed, stream);
+    return mh_launch_lora_dx(wsp, sbf, N, sp, (long)M * N, loraA, dxn, border_out, M, D, R2, s, p, seed, stream);
   }
   if (!dx_ext_buf) return MH_ERR_ARG;
   const int rc = mh_gemm_bf16_nt(A, lda, Bw, ldb, dx_ext_buf, N, M, N, K, nullptr, nullptr, 0, MH_GEMM_OUT_F32, 1.0f, stream);
   if (rc) return rc;
-  return mh_launch_lora_dx(dx_ext_buf, N, 1, 0, loraA, dxn, nullptr, M, D, R2, s, p, seed, stream);
+  return mh_launch_lora_dx(dx_ext_buf, 0, N, 1, 0, loraA, dxn, nullptr, M, D, R2, s, p, seed, stream);
 }
 
 int mh_launch_attn_rope_bwd(const void* qkv, int ld, const void* o, int ldo, const void* dout, int dout_is_bf16, int nslab,
@@ -721,9 +735,10 @@ extern "C" int mh_gemm_attn_rope_bwd(const void* A, int lda, const void* Bw, int
     const int tps = (nt + sp - 1) / sp;
     sp = (nt + tps - 1) / tps;
     float* wsp = ws_for(stream);
-    const int rc = run_splitk(g, splits, wsp, stream, /*reduce=*/false);
+    int sbf = 0;
+    const int rc = run_splitk(g, splits, wsp, stream, /*reduce=*/false, &sbf);
     if (rc) return rc;
-    return mh_launch_attn_rope_bwd(qkv, ld, o, ldo, wsp, 0, sp, (long)M * N, N, lse, dqkv, pos, cos_tab, sin_tab, kv_len, B, H, S,
+    return mh_launch_attn_rope_bwd(qkv, ld, o, ldo, wsp, sbf, sp, (long)M * N, N, lse, dqkv, pos, cos_tab, sin_tab, kv_len, B, H, S,
                                    D, scale, stream);
   }
   const int rc = mh_gemm_bf16_nt(A, lda, Bw, ldb, do_buf, N, M, N, K, nullptr, nullptr, 0, 0, 1.0f, stream);

@@ -139,7 +139,9 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(const bf16_t* __restri
   const int nt_all = K / G2_BK;
   const int kt0 = blockIdx.y * kt_per_split;
   const int nt = (nt_all - kt0) < kt_per_split ? (nt_all - kt0) : kt_per_split;
-  if (gridDim.y > 1) Cv = reinterpret_cast<float*>(Cv) + blockIdx.y * split_stride;
+  if (gridDim.y > 1)                                   // split_stride in elements of the slab type (fp32, or bf16 without OUT_F32)
+    Cv = (flags & MH_GEMM_OUT_F32) ? (void*)(reinterpret_cast<float*>(Cv) + blockIdx.y * split_stride)
+                                   : (void*)(reinterpret_cast<bf16_t*>(Cv) + blockIdx.y * split_stride);
 
   auto issue = [&](int t) {
     char* sA = smem + (t & 3) * G2_STAGE;

@@ -106,14 +106,14 @@ __global__ __launch_bounds__(LD_NW * 64) void lora_down_kernel(const bf16_t* __r
 // A thread keeps ITS four columns of all R2 rows of A in registers and walks a chunk of token rows: A is read once
 // per workgroup (64 KiB) instead of once per token row (the first version re-read the 256 KiB of A for every one of the
 // 1184 rows: 300 MB of L2 traffic, 19 us for a 39 MB kernel).  The R2 per-row scalars are wave-uniform (scalar loads).
-// nslab > 1: dx_ext is the first of nslab fp32 split-K slabs (stride `slab` floats) of the dgrad GEMM: they are summed here, in
+// nslab > 1: dx_ext is the first of nslab split-K slabs (fp32, or bf16 with sbf; stride `slab` elements) of the dgrad GEMM: summed here, in
 // slab order, exactly as splitk_reduce_kernel would have (one launch and one pass over [M, D+64] less); the summed border
 // d(s*t) [M, 64] is written to border_out for the weight-gradient kernel.
 template <int R2>
-__global__ __launch_bounds__(256) void lora_dx_kernel(const float* __restrict__ dx_ext, long ld, const float* __restrict__ A,
+__global__ __launch_bounds__(256) void lora_dx_kernel(const void* __restrict__ dx_ext, long ld, const float* __restrict__ A,
                                                       float* __restrict__ out, int M, int D, float s, float p,
                                                       unsigned long long seed, int rows_per, int nslab, long slab,
-                                                      float* __restrict__ border_out) {
+                                                      float* __restrict__ border_out, int sbf) {
   const float ik = 1.f / (1.f - p);
   const int d = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (d >= D) return;
@@ -123,22 +123,28 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(const float* __restrict__ 
   const int m0 = blockIdx.y * rows_per;
   const int m1 = (m0 + rows_per) < M ? (m0 + rows_per) : M;
   for (int m = m0; m < m1; ++m) {
-    const float* row = dx_ext + (long)m * ld;
+    const long r0 = (long)m * ld;                   // element offset of the row in a slab (fp32, or bf16: sbf)
     float g[R2];
 #pragma unroll
-    for (int j = 0; j < R2; ++j) g[j] = row[D + j];
-    float4_t base = *reinterpret_cast<const float4_t*>(row + d);
+    for (int j = 0; j < R2; j += 4) {
+      const float4_t t = slab_load4(dx_ext, r0 + D + j, sbf);
+      g[j] = t[0]; g[j + 1] = t[1]; g[j + 2] = t[2]; g[j + 3] = t[3];
+    }
+    float4_t base = slab_load4(dx_ext, r0 + d, sbf);
     for (int k = 1; k < nslab; ++k) {
-      const float* rk = row + (long)k * slab;
+      const long rk = r0 + (long)k * slab;
 #pragma unroll
-      for (int j = 0; j < R2; ++j) g[j] += rk[D + j];
-      const float4_t bk = *reinterpret_cast<const float4_t*>(rk + d);
+      for (int j = 0; j < R2; j += 4) {
+        const float4_t t = slab_load4(dx_ext, rk + D + j, sbf);
+        g[j] += t[0]; g[j + 1] += t[1]; g[j + 2] += t[2]; g[j + 3] += t[3];
+      }
+      const float4_t bk = slab_load4(dx_ext, rk + d, sbf);
       base[0] += bk[0]; base[1] += bk[1]; base[2] += bk[2]; base[3] += bk[3];
     }
-    if (border_out && blockIdx.x == 0 && threadIdx.x < R2) {
-      float v = row[D + threadIdx.x];
-      for (int k = 1; k < nslab; ++k) v += row[(long)k * slab + D + threadIdx.x];
-      border_out[(long)m * 64 + threadIdx.x] = v;
+    if (border_out && blockIdx.x == 0 && threadIdx.x == 0) {
+#pragma unroll
+      for (int j = 0; j < R2; j += 4)
+        *reinterpret_cast<float4_t*>(border_out + (long)m * 64 + j) = (float4_t){g[j], g[j + 1], g[j + 2], g[j + 3]};
     }
     float4_t acc = (float4_t){0.f, 0.f, 0.f, 0.f}, accv = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -337,8 +343,8 @@ extern "C" int mh_lora_down(const void* x, long ldx, const float* A, void* borde
   return MH_OK;
 }
 
-int mh_launch_lora_dx(const float* dx_ext, long ld, int nslab, long slab, const float* A, float* out, float* border_out, int M,
-                      int D, int R2_, float s, float p, unsigned long long seed, hipStream_t stream) {
+int mh_launch_lora_dx(const void* dx_ext, int slab_bf16, long ld, int nslab, long slab, const float* A, float* out, float* border_out,
+                      int M, int D, int R2_, float s, float p, unsigned long long seed, hipStream_t stream) {
   if (M <= 0) return MH_OK;
   if (D % 4 || ld % 4 || ld < D + R2_ || p < 0.f || p >= 1.f || nslab < 1 || R2_ > 64) return MH_ERR_ARG;
   const int col_blocks = (D / 4 + 255) / 256;
@@ -346,14 +352,14 @@ int mh_launch_lora_dx(const float* dx_ext, long ld, int nslab, long slab, const 
   row_chunks = row_chunks < 1 ? 1 : (row_chunks > M ? M : row_chunks);
   const int rows_per = (M + row_chunks - 1) / row_chunks;
   LORA_DISPATCH(R2_, hipLaunchKernelGGL(lora_dx_kernel<R2>, dim3(col_blocks, (M + rows_per - 1) / rows_per), dim3(256), 0,
-                                        stream, dx_ext, ld, A, out, M, D, s, p, seed, rows_per, nslab, slab, border_out));
+                                        stream, dx_ext, ld, A, out, M, D, s, p, seed, rows_per, nslab, slab, border_out, slab_bf16));
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
 
 extern "C" int mh_lora_dx(const float* dx_ext, long ld, const float* A, float* out, int M, int D, int R2_, float s,
                           float p, unsigned long long seed, hipStream_t stream) {
-  return mh_launch_lora_dx(dx_ext, ld, 1, 0, A, out, nullptr, M, D, R2_, s, p, seed, stream);
+  return mh_launch_lora_dx(dx_ext, 0, ld, 1, 0, A, out, nullptr, M, D, R2_, s, p, seed, stream);
 }
 
 extern "C" long mh_lora_wgrad_ws_floats(int D, int R2_) { return (long)LR_CH * (2L * R2_ * D); }

@@ -37,21 +37,21 @@ __global__ __launch_bounds__(NT) void rmsnorm_fwd_kernel(const float* __restrict
 // so each operand is read once.  dy may be given as `nslab` split-K partial slabs [nslab][M][ldy] of the dgrad GEMM that
 // produced it (mh_gemm_rmsnorm_bwd): they are summed in slab order exactly as splitk_reduce_kernel sums them, which makes
 // the fused form bit-identical to GEMM -> reduce -> rmsnorm_bwd while skipping one launch and a write + read of dy.
-__global__ __launch_bounds__(NT) void rmsnorm_bwd_kernel(const float* __restrict__ dy, int nslab, long slab, long ldy,
+__global__ __launch_bounds__(NT) void rmsnorm_bwd_kernel(const void* __restrict__ dy, int nslab, long slab, long ldy,
                                                          const float* __restrict__ x, const float* __restrict__ w,
-                                                         const float* dres, float* dx, bf16_t* dx_bf, int D, float eps) {
+                                                         const float* dres, float* dx, bf16_t* dx_bf, int D, float eps, int sbf) {
   __shared__ float red[NW];
   const size_t row = blockIdx.x;
   const float* xr = x + row * D;
-  const float* gr = dy + row * ldy;
+  const long g0 = (long)row * ldy;                 // element offset of this row in a slab (fp32 or bf16: sbf)
   float4_t xv[8], gv[8];
   float ss = 0.f, dot = 0.f;
   int c = 0;
   for (int i = threadIdx.x * 4; i < D; i += NT * 4, ++c) {
     const float4_t v = *reinterpret_cast<const float4_t*>(xr + i);
-    float4_t g = *reinterpret_cast<const float4_t*>(gr + i);
+    float4_t g = slab_load4(dy, g0 + i, sbf);
     for (int k = 1; k < nslab; ++k) {
-      const float4_t p = *reinterpret_cast<const float4_t*>(gr + (long)k * slab + i);
+      const float4_t p = slab_load4(dy, g0 + (long)k * slab + i, sbf);
       g[0] += p[0]; g[1] += p[1]; g[2] += p[2]; g[3] += p[3];
     }
     if (nslab > 1) { g[0] *= 1.0f; g[1] *= 1.0f; g[2] *= 1.0f; g[3] *= 1.0f; }   // splitk_reduce_kernel's alpha
@@ -193,12 +193,12 @@ extern "C" int mh_rmsnorm_fwd(const float* x, const float* w, void* y_bf16, long
 }
 
 // dy as nslab partial slabs [nslab][M][ldy] (nslab = 1: a plain [M, ldy] matrix); called from gemm.hip too
-int mh_launch_rmsnorm_bwd(const float* dy, int nslab, long slab, long ldy, const float* x, const float* w, const float* dres,
-                          float* dx, void* dx_bf16, int M, int D, float eps, hipStream_t stream) {
+int mh_launch_rmsnorm_bwd(const void* dy, int slab_bf16, int nslab, long slab, long ldy, const float* x, const float* w,
+                          const float* dres, float* dx, void* dx_bf16, int M, int D, float eps, hipStream_t stream) {
   if (M <= 0) return MH_OK;
   if ((D % 4) || D > 8192 || (ldy % 4) || nslab < 1) return MH_ERR_ARG;
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(M), dim3(NT), 0, stream, dy, nslab, slab, ldy, x, w, dres, dx, (bf16_t*)dx_bf16, D,
-                     eps);
+                     eps, slab_bf16);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
@@ -206,7 +206,7 @@ int mh_launch_rmsnorm_bwd(const float* dy, int nslab, long slab, long ldy, const
 extern "C" int mh_rmsnorm_bwd(const float* dy, const float* x, const float* w, const float* dres, float* dx,
                               void* dx_bf16, int M, int D, float eps, hipStream_t stream) {
   if (M <= 0) return MH_OK;
-  return mh_launch_rmsnorm_bwd(dy, 1, 0, D, x, w, dres, dx, dx_bf16, M, D, eps, stream);
+  return mh_launch_rmsnorm_bwd(dy, 0, 1, 0, D, x, w, dres, dx, dx_bf16, M, D, eps, stream);
 }
 
 extern "C" int mh_layernorm_fwd(const float* x, const float* w, const float* b, void* y_bf16, float* y_f32, int M,

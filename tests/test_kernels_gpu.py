@@ -39,7 +39,7 @@ def test_gemm_plain(M, N, K, regstage):
     b = bf(rnd(N, K, seed=2) + torch.arange(N)[:, None] * 1e-3).to(DEV)
     ref = a.float() @ b.float().T
     out = ops.gemm(a, b, out_dtype=torch.float32, regstage=regstage)
-    assert relerr(out, ref) < 2e-5 * math.sqrt(K) + 1e-6
+    assert relerr(out, ref) < (2e-5 * math.sqrt(K) + 1e-6 if regstage else slab_tol(M, N, K, 2e-5 * math.sqrt(K) + 1e-6))
     out_b = ops.gemm(a, b, regstage=regstage)
     assert relerr(out_b.float(), ref) < 6e-3
 
@@ -83,25 +83,47 @@ def test_gemm_splitk_wgrad_shapes(M, N, K):
     assert relerr(wide[:, 4:4 + N], ref) < 1e-4 and wide[:, :4].abs().max() == 0
 
 
+def slab_tol(M, N, K, tight):
+    """Accuracy bound of an automatically split product against fp32 math: the 256x256 kernel's partial slabs are bf16 (one
+    2^-9 rounding per partial sum, csrc/gemm.hip run_splitk) -- the bit-identity of fused and unfused forms is unaffected."""
+    kernel, splits = ops.gemm_plan(M, N, K)
+    return 4e-3 if (kernel == 2 and splits > 1) else tight
+
+
+def _slab_hook():
+    import ctypes
+    from myriad_amd import _lib as L
+    return ctypes.CDLL(L.LIB_PATH).mhdbg_set_slab_bf16
+
+
+@pytest.mark.parametrize("slab_bf16", [1, 0])
 @pytest.mark.parametrize("M,N,K", [(1184, 4096, 11008), (2056, 1408, 6144), (648, 768, 3072)])
-def test_gemm_auto_splitk_epilogue(M, N, K):
+def test_gemm_auto_splitk_epilogue(M, N, K, slab_bf16):
     """With a registered workspace mh_gemm_bf16_nt splits K for under-filled shapes; the epilogue moves into the
-    reduce pass and must give the same results (bias + GELU + residual, bf16 and f32 out, in-place accumulate)."""
+    reduce pass and must give the same results (bias + GELU + residual, bf16 and f32 out, in-place accumulate).
+    The 256x256 kernel's partial slabs are bf16 by default (one 2^-9 rounding per partial sum: the product is then as exact as
+    a bf16 GEMM output, not as an fp32 one); MYRIAD_SLAB_BF16=0 / the debug hook keep them fp32."""
     ops.ensure_workspace(DEV)
-    a = bf(rnd(M, K, seed=9)).to(DEV)
-    b = bf(rnd(N, K, seed=10) * 0.05).to(DEV)
-    bias = rnd(N, seed=11).to(DEV)
-    res = rnd(M, N, seed=12).to(DEV)
-    ref = a.float() @ b.float().T
-    o = ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32)
-    assert relerr(o, ref + bias + res) < 1e-4
-    o_plain = ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32, variant=1)   # forced single-pass kernel
-    assert relerr(o, o_plain) < 1e-5
-    ob = ops.gemm(a, b, bias=bias, gelu=True)
-    assert relerr(ob.float(), F.gelu(ref + bias)) < 6e-3
-    acc = res.clone()
-    ops.gemm(a, b, out=acc, residual=acc)
-    assert relerr(acc, ref + res) < 1e-4
+    hook = _slab_hook()
+    hook(slab_bf16)
+    try:
+        lossy = bool(slab_bf16) and ops.gemm_plan(M, N, K)[0] == 2
+        a = bf(rnd(M, K, seed=9)).to(DEV)
+        b = bf(rnd(N, K, seed=10) * 0.05).to(DEV)
+        bias = rnd(N, seed=11).to(DEV)
+        res = rnd(M, N, seed=12).to(DEV)
+        ref = a.float() @ b.float().T
+        o = ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32)
+        assert relerr(o, ref + bias + res) < (4e-3 if lossy else 1e-4)
+        o_plain = ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32, variant=1)   # forced single-pass kernel
+        assert relerr(o, o_plain) < (4e-3 if lossy else 1e-5)
+        ob = ops.gemm(a, b, bias=bias, gelu=True)
+        assert relerr(ob.float(), F.gelu(ref + bias)) < 6e-3
+        acc = res.clone()
+        ops.gemm(a, b, out=acc, residual=acc)
+        assert relerr(acc, ref + res) < (4e-3 if lossy else 1e-4)
+    finally:
+        hook(1)
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 12288, 4160), (16, 1000, 11008), (3, 32000, 4096)])
@@ -158,7 +180,7 @@ def test_gemm_residual_rmsnorm_is_bit_identical_to_two_launches(M, N, K):
     wide = torch.zeros(M, N + 64, dtype=torch.bfloat16, device=DEV)       # the bordered LoRA operand: strided y
     h2, y2 = ops.gemm_residual_rmsnorm(a, b, res, w, 1e-6, y_out=wide[:, :N])
     assert torch.equal(h2, h_ref) and torch.equal(wide[:, :N], y_ref) and wide[:, N:].abs().max() == 0
-    assert relerr(h, a.float() @ b.float().T + res) < 1e-4
+    assert relerr(h, a.float() @ b.float().T + res) < slab_tol(M, N, K, 1e-4)
 
 
 @pytest.mark.parametrize("M,N,K", [(2056, 1408, 6144), (2056, 1408, 1408), (300, 512, 256)])
@@ -196,7 +218,7 @@ def test_gemm_rmsnorm_bwd_is_bit_identical_to_two_launches(M, N, K):
     xt = x.clone().requires_grad_(True)
     y = xt * torch.rsqrt(xt.pow(2).mean(-1, keepdim=True) + 1e-6) * w
     y.backward(a.float() @ b.float().T)
-    assert relerr(dx, xt.grad + dres) < 2e-4
+    assert relerr(dx, xt.grad + dres) < slab_tol(M, N, K, 2e-4)
 
 
 def test_gemm_rejects_bad_k():

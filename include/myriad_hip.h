@@ -44,6 +44,16 @@ int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int
  * For profilers and benchmarks that attribute time per kernel. */
 int mh_gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits);
 
+/* Launch profiler (`roofline.achieved` is per launch of the dominant kernel): between mh_prof_start and
+ * mh_prof_stop every launch of gemm_256_kernel / gemm_nt_kernel is bracketed by two HIP events on the stream it is launched
+ * on -- the kernel alone, also when it is the partial-product launch of a split-K op.  Launches inside a stream capture are
+ * skipped.  mh_prof_stop waits for the device and writes, per recorded launch i, meta[6i..6i+5] = (kernel id as
+ * mh_gemm_plan numbers them, M, N, K, K splits, flags) and ms[i]; returns the number of records (<= cap).  The events
+ * (2 per record) are created once and reused.  One host thread.  Both calls launch a one-wave no-op kernel
+ * (mh_prof_marker_kernel) on `s`, so that a rocprofv3 kernel trace of the same run shows where the profiled region lies. */
+int mh_prof_start(int capacity, mh_stream_t s);
+int mh_prof_stop(int* meta, float* ms, int cap, mh_stream_t s);
+
 /* Linear + residual add + the RMSNorm that consumes the sum (modeling_llama.py:281-293 then :66-74 of the next block):
  * H[M,N] = A.B^T + residual (f32, the new residual stream), Y[M,N] = bf16(norm_w * H * rsqrt(mean(H^2) + eps)).
  * When the GEMM is split along K the slab reduction, the residual add and the norm run as ONE kernel; otherwise this is

@@ -237,6 +237,9 @@ def optimizer_state_dict(store, lr: float, weight_decay: float = 0.05, betas=(0.
     (runner_base.py:104-139): indices follow the reference's named_parameters() order, NOT the flat buffer's; a module
     that was never stepped has no state entry (torch creates state lazily), each entry carries its module's own step."""
     from .myriad import module_of
+    if not getattr(store, "moments_complete", True):
+        raise RuntimeError("optimizer_state_dict: this rank holds Adam moments for its own shard only (DataParallel mode "
+                           "'rs_ag'); call dp.gather_state(store) on every rank first")
     order, n_wd = _optimizer_index(store)
     ishape = {n: i for n, i, _ in store.specs}
     rshape = {n: r for n, _, r in store.specs}
@@ -297,9 +300,13 @@ class CheckpointManager:
         os.makedirs(output_dir, exist_ok=True)
 
     def save(self, model, cur_epoch, lr: float, weight_decay: float = 0.05, config: Optional[dict] = None,
-             is_best: bool = False) -> str:
+             is_best: bool = False, dp=None) -> str:
+        """`dp`: the DataParallel in use.  In mode 'rs_ag' the Adam moments are sharded; with `dp` the gather (a collective:
+        every rank must then call save) happens here, without it a save of incomplete moments raises instead of writing them."""
         if hasattr(model, "finish_update"):
             model.finish_update()                      # an overlapped optimiser step must land before parameters are read
+        if dp is not None and not getattr(model.store, "moments_complete", True):
+            dp.gather_state(model.store)
         save_obj = {"model": model.state_dict(),       # trainable parameters only, reference key names and layouts
                     "optimizer": optimizer_state_dict(model.store, lr, weight_decay),
                     "config": config or {}, "scaler": None, "epoch": cur_epoch}

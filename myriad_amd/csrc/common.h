@@ -20,6 +20,11 @@ typedef __attribute__((ext_vector_type(16))) float float16_t;
     if (e__ != hipSuccess) return MH_ERR_LAUNCH;            \
   } while (0)
 
+// launch profiler (prof.hip): no-ops unless mh_prof_start() was called
+extern bool g_mh_prof_on;
+void mh_prof_pre(hipStream_t s, int kernel, int M, int N, int K, int splits, int flags);
+void mh_prof_post(hipStream_t s);
+
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 
 // round-to-nearest-even fp32 -> bf16 (NaN stays NaN)

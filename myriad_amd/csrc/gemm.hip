@@ -265,10 +265,12 @@ static int launch_gemm(const GemmArgs& g, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     attr_set = true;
   }
+  if (g_mh_prof_on) mh_prof_pre(stream, TBN == 64 ? 3 : 1, g.M, g.N, g.K, g.splits, g.flags);
   // tps / kt_per_split are in units of 64-deep K tiles at the call sites; rescale for 32-deep kernels
   hipLaunchKernelGGL((gemm_nt_kernel<STAGING, NST, TBN, MINB, TBK, NW>), grid, block, shmem, stream, (const bf16_t*)g.A,
                      (const bf16_t*)g.B, g.C, g.bias, g.residual, g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.ldr, g.flags,
                      g.alpha, tiles_m, g.tps * (64 / TBK), g.split_stride);
+  if (g_mh_prof_on) mh_prof_post(stream);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

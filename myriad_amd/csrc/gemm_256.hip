@@ -407,12 +407,14 @@ int mh_launch_gemm_256(const void* A, int lda, const void* B, int ldb, void* C, 
     attr_set = true;
   }
   const dim3 grid(tiles_m * tiles_n, splits), block(512);
+  if (g_mh_prof_on) mh_prof_pre(stream, 2, M, N, K, splits, flags);
   if (g2_trace)
     hipLaunchKernelGGL((gemm_256_kernel<true>), grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)B, C, bias,
                        residual, M, N, K, lda, ldb, ldc, ldr, flags, alpha, tiles_m, tps * 2, split_stride, g2_trace, aux, ldaux);
   else
     hipLaunchKernelGGL((gemm_256_kernel<false>), grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)B, C, bias,
                        residual, M, N, K, lda, ldb, ldc, ldr, flags, alpha, tiles_m, tps * 2, split_stride, nullptr, aux, ldaux);
+  if (g_mh_prof_on) mh_prof_post(stream);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

@@ -87,7 +87,13 @@ class ParamStore:
                 else:
                     self.ranges.append((mi, off, off + ops.round_up(n, 4), decays))
                 off += ops.round_up(n, 4)
+        # padded to a multiple of 32 elements: at 2 / 4 / 8 ranks the reduce-scatter / all-gather shards (multiples of 4
+        # elements) tile the buffer exactly, so DataParallel mode 'rs_ag' never pads or copies it (the tail belongs to no
+        # module range: zero gradient, never updated)
+        self.n_used = off                                         # the parameters proper end here
+        off = ops.round_up(off, 32)
         self.total = off
+        self.moments_complete = True                              # False while Adam moments exist for this rank's shard only
         nm = len(self.modules)
         self.flat_p = torch.zeros(off, dtype=F32, device=self.dev)
         self.flat_g_comm = torch.zeros(off + ops.round_up(max(nm, 1), 4), dtype=F32, device=self.dev)   # what DP exchanges
@@ -129,6 +135,8 @@ class ParamStore:
         this step are left alone (see class docstring).  `shard` = (lo, hi): update only that slice of the flat buffer
         (DataParallel mode 'rs_ag': each rank owns 1/world of the optimiser state)."""
         self.step += 1
+        if shard is not None and (shard[0] > 0 or shard[1] < self.total):
+            self.moments_complete = False                         # DataParallel.gather_state() restores it
         for mi, a, b, decays in self.ranges:
             if shard is not None:
                 a, b = max(a, shard[0]), min(b, shard[1])

@@ -95,7 +95,16 @@ class DataParallel:
         if use_side_stream and device is not None and torch.device(device).type == "cuda" and self.world > 1:
             self.side = torch.cuda.Stream(device=device)
         self._pending = None
+        self._bufs = {}
         self._gloo = dist.is_initialized() and dist.get_backend() == "gloo"
+
+    def _persistent(self, key: str, n: int, dtype, device) -> torch.Tensor:
+        """Exchange staging buffers are allocated once per (purpose, size, dtype) and reused every step."""
+        k = (key, n, dtype, str(device))
+        buf = self._bufs.get(k)
+        if buf is None:
+            buf = self._bufs[k] = torch.zeros(n, dtype=dtype, device=device)
+        return buf
 
     # ---- shard geometry (rs_ag): [0, total) split into `world` equal pieces of a multiple of 4 elements
     def shard(self, total: int):
@@ -131,13 +140,17 @@ class DataParallel:
     def _reduce_scatter(self, body: torch.Tensor, per: int) -> None:
         """Sum over ranks; rank r ends up with the sum in body[r*per:(r+1)*per] (the rest of `body` is left unspecified)."""
         n = body.numel()
-        padded = body if n == per * self.world else torch.cat([body, body.new_zeros(per * self.world - n)])
+        if n == per * self.world:                         # the store pads its buffers so that this holds at 2 / 4 / 8 ranks
+            padded = body
+        else:                                             # other rank counts: one persistent padded copy, no per-step allocation
+            padded = self._persistent("rs_pad", per * self.world, body.dtype, body.device)
+            padded[:n].copy_(body)
         w = self._cast(padded, self.grad_dtype)
         if self._gloo:                                    # gloo has no reduce_scatter: all-reduce and keep the own piece
             self.dist.all_reduce(w, op=self.dist.ReduceOp.SUM)
             mine = w[self.rank * per:(self.rank + 1) * per]
         else:
-            mine = torch.empty(per, dtype=w.dtype, device=w.device)
+            mine = self._persistent("rs_mine", per, w.dtype, w.device)
             self.dist.reduce_scatter_tensor(mine, w, op=self.dist.ReduceOp.SUM)
         lo, hi, _ = self.shard(n)
         body[lo:hi].copy_(self._cast(mine, body.dtype)[:hi - lo])
@@ -185,12 +198,15 @@ class DataParallel:
             full = torch.cat(parts)[:n]
             flat_p.copy_(full)
         else:
-            self.dist.all_gather_into_tensor(flat_p, flat_p[lo:hi].clone())   # a copy: input and output may not alias
+            mine = self._persistent("ag_mine", per, flat_p.dtype, flat_p.device)
+            mine.copy_(flat_p[lo:hi])                     # a copy: input and output may not alias
+            self.dist.all_gather_into_tensor(flat_p, mine)
 
     def gather_state(self, store) -> None:
-        """rs_ag: collect the Adam moments of every shard (before a checkpoint is written)."""
+        """rs_ag: collect the Adam moments of every shard (before a checkpoint is written).  A collective: every rank calls it."""
         self.gather_params(store.flat_m)
         self.gather_params(store.flat_v)
+        store.moments_complete = True
 
     def barrier(self):
         if self.world > 1:

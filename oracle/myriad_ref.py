@@ -223,6 +223,17 @@ def decoder_mask(attention_mask: Tensor, q_len: int, past_len: int, dtype=torch.
     return e if m is None else e + m
 
 
+def lora_linear(x: Tensor, W: Tensor, A: Tensor, Bm: Tensor, alpha: float, r: int,
+                dropout_mask: Optional[Tensor] = None) -> Tensor:
+    """peft's published `lora.Linear.forward` for the wrap at myriad.py:170-180 (PARITY UNPINNED by the reference: peft
+    is un-vendored and absent; pinned instead by the hand-computed known-answer vectors in
+    tests/test_oracle_golden.py::test_peft_lora_formula_known_answer):
+        y = x W^T + (alpha / r) * (drop(x) A^T) B^T,      drop(x) = x * keep / (1 - p)   (nn.Dropout, training mode)
+    `dropout_mask` holds the keep/(1-p) factors (None = eval mode / p = 0)."""
+    xin = x if dropout_mask is None else x * dropout_mask
+    return F.linear(x, W) + (alpha / r) * F.linear(F.linear(xin, A), Bm)
+
+
 def llama_layer(sd: SD, p: str, x: Tensor, mask: Tensor, position_ids: Tensor, heads: int,
                 eps: float, cos: Tensor, sin: Tensor, past=None, lora: Optional[dict] = None):
     """`LlamaDecoderLayer.forward` modeling_llama.py:247-299 with `LlamaAttention.forward`
@@ -238,16 +249,14 @@ def llama_layer(sd: SD, p: str, x: Tensor, mask: Tensor, position_ids: Tensor, h
     h = rms_norm(x, sd[p + "input_layernorm.weight"], eps)
 
     def proj(name, inp):
-        y = F.linear(inp, sd[p + f"self_attn.{name}.weight"])
+        W = sd[p + f"self_attn.{name}.weight"]
         ka = p + f"self_attn.{name}.lora_A.default.weight"
-        if lora is not None and ka in sd:
-            xin = inp
-            dm = lora.get("dropout_mask")
-            if dm is not None:
-                xin = inp * (dm[name] if isinstance(dm, dict) else dm)
-            y = y + (lora["alpha"] / lora["r"]) * F.linear(
-                F.linear(xin, sd[ka]), sd[p + f"self_attn.{name}.lora_B.default.weight"])
-        return y
+        if lora is None or ka not in sd:
+            return F.linear(inp, W)
+        dm = lora.get("dropout_mask")
+        if isinstance(dm, dict):
+            dm = dm[name]
+        return lora_linear(inp, W, sd[ka], sd[p + f"self_attn.{name}.lora_B.default.weight"], lora["alpha"], lora["r"], dm)
 
     q = proj("q_proj", h).view(B, S, heads, d).transpose(1, 2)
     k = proj("k_proj", h).view(B, S, heads, d).transpose(1, 2)

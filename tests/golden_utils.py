@@ -151,6 +151,69 @@ def decode_chain_inputs(rows) -> torch.Tensor:
     return x
 
 
+# ---- peaked FULL-PIPELINE decode fixture: ViT (1 block) -> adaptor -> ln_vision -> Q-Former (2 layers,
+# 81 queries) -> llama_proj + VETokenizer -> prompt_wrap -> LLaMA (1 layer, full width, V = 32000) -> greedy decode, composed
+# from the reference's own modules as myriad.py:241-272,433-454 do.  Two engineered pieces make every arg-max decisive:
+#   * the FIRST generated token is chosen by the IMAGE: `probe` (committed data, tests/golden/pipeline_chain.npz) holds
+#     rows P_i with P_i . h_j = gamma * delta_ij for the reference's final hidden state h_j of batch row j at the last
+#     prompt position (gamma x the pseudo-inverse of those four states); lm_head[first token of row i] += P_i.  The four
+#     rows share one prompt, so only the image path (ViT / Q-Former / VE nets -> attention) tells them apart;
+#   * from then on the LLaMA is the token-transition machine of DECODE_CHAIN above, at width 4096.
+# Row 0's favourite first token is EOS (banned by min_length = 1), its chain ends in the eval script's two-token stop.
+PIPELINE_CHAIN = dict(vocab=32000, vit=711, qf=712, llm=713, ad=714, glue=715, batch=716, dirs=717, gamma=24.0)
+PIPELINE_CHAINS = {
+    "row0": list(range(100, 131)) + [2277, 29937],
+    "row1": list(range(200, 246)),
+    "row2": [300, 301, 302, 303, 2],
+    "row3": [400, 401, 835, 402] + list(range(403, 440)),
+}
+
+
+def pipeline_chain_weights(probe=None) -> Dict[str, torch.Tensor]:
+    c = PIPELINE_CHAIN
+    D, V = 4096, c["vocab"]
+    sd = {}
+    sd.update(vit_weights(1408, 1, 16, int(1408 * 4.3637), 14, 257, seed=c["vit"]))
+    sd.update(qformer_weights(768, 2, 3072, 1408, seed=c["qf"]))
+    sd.update(llama_weights(D, 1, 11008, V, seed=c["llm"]))
+    sd.update(adapter_weights(seed=c["ad"]))
+    sd.update(glue_weights(seed=c["glue"]))
+    g = torch.Generator().manual_seed(c["dirs"])
+    emb = sd["llama_model.model.embed_tokens.weight"]
+    lm = sd["llama_model.lm_head.weight"]
+    used = sorted({t for ch in PIPELINE_CHAINS.values() for t in ch})
+    dirs = {}
+    for t in used:
+        v = torch.randn(D, generator=g)
+        dirs[t] = v / v.norm()
+        emb[t] = dirs[t] * math.sqrt(D) * 2.0
+    for ch in PIPELINE_CHAINS.values():
+        for a, b in zip(ch[:-1], ch[1:]):
+            lm[b] += 2.5 * dirs[a]
+    if probe is not None:
+        probe = torch.as_tensor(probe, dtype=torch.float32)
+        for i, name in enumerate(("row0", "row1", "row2", "row3")):
+            lm[PIPELINE_CHAINS[name][0]] += probe[i]
+        lm[2] += 1.25 * probe[0]          # EOS is row 0's favourite first token; min_length = 1 bans it
+    return sd
+
+
+def pipeline_chain_batch():
+    """4 images N(0,1); 4 anomaly maps with a bump at a row-specific place (noise maps pool to the same statistics in
+    every row); one shared prompt (4 ids before / 28 after <ImageHere>), as the eval script's fixed question gives."""
+    c = PIPELINE_CHAIN
+    g = torch.Generator().manual_seed(c["batch"])
+    image = torch.randn(4, 3, 224, 224, generator=g)
+    yy, xx = torch.meshgrid(torch.arange(224.0), torch.arange(224.0), indexing="ij")
+    maps = torch.rand(4, 1, 224, 224, generator=g) * 0.1
+    for i, (cy, cx, s) in enumerate(((40, 50, 18.0), (170, 60, 30.0), (112, 112, 45.0), (60, 180, 12.0))):
+        maps[i, 0] += 0.9 * torch.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s))
+    maps = maps.clamp_(0, 1)
+    before = torch.randint(3000, 29000, (1, 4), generator=g).expand(4, -1).contiguous()      # clear of the chain ids
+    after = torch.randint(3000, 29000, (1, 28), generator=g).expand(4, -1).contiguous()
+    return image, maps, before, after
+
+
 def ve_stem_weights(prefix: str, g, sd, dim_in: int = 1):
     c = dim_in
     for idx in (0, 3, 6, 9, 12):

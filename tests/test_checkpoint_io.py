@@ -153,7 +153,7 @@ def test_checkpoint_round_trip_and_torch_adamw_compat(tmp_path):
     m2.store.set_module_steps({})
     assert C.CheckpointManager.load(m2, paths[-1]) == 3                            # resume at epoch + 1
     for a, b in ((m.store.flat_p, m2.store.flat_p), (m.store.flat_m, m2.store.flat_m), (m.store.flat_v, m2.store.flat_v)):
-        assert torch.equal(a, b)
+        assert torch.equal(a[:m.store.n_used], b[:m.store.n_used])          # past n_used: exchange padding, not parameters
     assert m2.store.module_steps() == m.store.module_steps() and m2.store.step == 17
     with pytest.raises(RuntimeError):
         C.CheckpointManager.load(m2, str(tmp_path / "nope.pth"))

@@ -71,6 +71,73 @@ def test_loss_is_independent_of_batch_composition(model):
     assert abs(pair - (singles[1] + singles[2]) / 2) < 2e-3 * abs(pair)
 
 
+def test_benchmark_shape_b8_is_deterministic_and_batch_independent(model):
+    """The bench.py shape itself: 8 images per GPU, B*S = 1184 rows (the 256x256 kernel's 5 clamped row tiles, its K splits
+    and slab-summing consumers, the 430-tile gate|up launch).  Bit-identical run to run; the batch-8 loss is the mean of
+    the eight batch-1 losses and of the two batch-4 halves (M = 148 and 592 pick other kernels and split counts)."""
+    s = samples(8, seed=21)
+    l1, g1 = loss_and_grad(model, s)
+    l2, g2 = loss_and_grad(model, s)
+    assert l1 == l2 and torch.equal(g1, g2)
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    with torch.no_grad():
+        full = float(model._forward_impl(s, False))
+        singles = [float(model._forward_impl(pick(s, slice(i, i + 1)), False)) for i in range(8)]
+        halves = [float(model._forward_impl(pick(s, slice(i, i + 4)), False)) for i in (0, 4)]
+    assert abs(full - sum(singles) / 8) < 2e-3 * abs(full), (full, singles)
+    assert abs(full - sum(halves) / 2) < 2e-3 * abs(full), (full, halves)
+    # the gradient of the batch-8 mean loss is the mean of the two half-batch gradients (linearity of the backward)
+    _, ga = loss_and_grad(model, pick(s, slice(0, 4)))
+    _, gb = loss_and_grad(model, pick(s, slice(4, 8)))
+    gm = (ga + gb) / 2
+    assert float((g1 - gm).abs().max()) < 3e-2 * float(g1.abs().max())
+
+
+def test_benchmark_shape_b8_train_step_with_lora_dropout(model):
+    """One full optimisation step at the bench shape with `use_lora` and peft's dropout (p = 0.05) ON: finite, repeatable
+    from the same state and step seed, the dropout changes the loss, and the LoRA / adapter parameters move."""
+    st, lora = model.store, model.lora
+    keep = (st.flat_p.clone(), st.flat_m.clone(), st.flat_v.clone(), st.step, st.steps_dev.clone(), lora.p, lora.step_seed)
+    s = samples(8, seed=22)
+
+    def restore():
+        st.flat_p.copy_(keep[0]); st.flat_m.copy_(keep[1]); st.flat_v.copy_(keep[2]); st.step = keep[3]; st.steps_dev.copy_(keep[4])
+        lora.step_seed = keep[6]
+
+    try:
+        # peft's B = 0 at init would make dropout invisible in the first forward: give B a value first
+        for i in range(len(model.llama.layers)):
+            for n in lora.names(i)[2:]:
+                st.p[n].normal_(0.0, 0.02, generator=torch.Generator(device=DEV).manual_seed(100 + i))
+        keep = (st.flat_p.clone(),) + keep[1:]
+        lora.p = 0.0
+        l_plain = float(model.train_step(s, 1e-3, 0.05))
+        restore()
+        lora.p = 0.05
+        l_a = float(model.train_step(s, 1e-3, 0.05))
+        torch.cuda.synchronize()
+        p_a = st.flat_p.clone()
+        restore()
+        l_b = float(model.train_step(s, 1e-3, 0.05))
+        torch.cuda.synchronize()
+        assert l_a == l_b and torch.equal(p_a, st.flat_p)        # same state + same step seed -> same masks -> same bits
+        assert l_a != l_plain and abs(l_a - l_plain) < 0.05 * abs(l_plain)
+        assert torch.isfinite(st.flat_p).all()
+        moved = (p_a - keep[0]).abs()
+        for n in (lora.names(0)[0], lora.names(31)[3], "expert_adaptor.conv1.weight"):
+            o, cnt = st.offsets[n]
+            assert float(moved[o:o + cnt].max()) > 0, n
+    finally:
+        lora.p = keep[5]
+        st.flat_p.zero_()
+        model_init = keep[0]
+        st.flat_p.copy_(model_init); st.flat_m.copy_(keep[1]); st.flat_v.copy_(keep[2]); st.step = keep[3]; st.steps_dev.copy_(keep[4])
+        lora.step_seed = keep[6]
+        for i in range(len(model.llama.layers)):                  # back to peft's B = 0
+            for n in lora.names(i)[2:]:
+                st.p[n].zero_()
+
+
 def test_graph_replayed_decode_equals_eager_decode(model):
     model.eval()
     try:

@@ -343,6 +343,33 @@ def test_myriad_generate_token_ids_vs_oracle(composite):
     assert checked >= 1, margins
 
 
+@pytest.mark.parametrize("sampled", [False, True])
+def test_myriad_generate_every_id_equals_the_reference_pipeline(sampled):
+    """The FULL `Myriad.generate` (myriad.py:433-454: ViT -> adaptor -> ln_vision -> Q-Former with the VEInstructor queries
+    -> llama_proj + VETokenizer tokens -> prompt_wrap without BOS -> prefill -> KV-cache decode) on the peaked pipeline
+    fixture made by the reference's own modules (tests/golden/pipeline_chain.npz, tools/make_golden.py:case_pipeline_chain).
+    The four rows share one prompt: the FIRST generated id of each row is decided by its image alone.  EVERY id must be
+    equal -- no margin gate -- at batch 4 (row-0 stop rule on [2277, 29937] after 33 tokens, a row finishing early on EOS,
+    a row emitting 835 without stopping), at batch 1, and for row 3 alone (where [835] does stop the call)."""
+    g = load("pipeline_chain")
+    sd = gu.pipeline_chain_weights(g["probe"])
+    image, maps, before, after = gu.pipeline_chain_batch()
+    model = MyriadHIP(sd, dict(need_backward=False), device=DEV)
+    model.eval()
+    kw = dict(do_sample=True, top_p=0.01, temperature=1.0) if sampled else {}
+    stops = ((835,), (2277, 29937))
+    for name, sel in (("b4", [0, 1, 2, 3]), ("b1", [0]), ("b1r3", [3])):
+        smp = dict(image=image[sel], anomaly_maps=maps[sel], before_ids=before[sel], after_ids=after[sel])
+        out = model.generate(smp, max_new_tokens=90, stop_ids=stops, min_length=1, **kw)
+        ids = out["token_ids"].cpu()
+        assert torch.equal(ids, g[name + "_ids"]), (name, ids, g[name + "_ids"])
+        st = model.last_generate_stats
+        assert st["steps"] == ids.shape[1] and st["sampled_rows"] == 0
+        if sampled:
+            assert st["min_pmax"] >= 0.5
+    assert g["b4_ids"][:, 0].tolist() == [100, 200, 300, 400]           # one first id per image
+
+
 def test_train_step_moves_parameters_like_adamw(composite):
     g, sd, batch = composite
     model = MyriadHIP(sd, dict(fixed_stage=1, fixed_taskstage=0), device=DEV)
@@ -514,3 +541,78 @@ def test_llama_lora_qv_vs_oracle(dropout):
     for n in lora_sd:
         want = osd[n.replace(PEFT_PREFIX, "llama_model.model.layers.")].grad
         assert relerr(st.g[n], want) < 6e-2, n
+
+
+@pytest.mark.parametrize("p", [0.0, 0.5])
+def test_lora_qv_known_answer_hand_computed(p):
+    """a-14 pinned independently of the oracle: peft's form  y = W x + (alpha/r) B A drop(x)  on q_proj / v_proj through the
+    library's own path (lora_down -> bordered qkv GEMM; bordered dgrad GEMM -> lora_dx / lora_wgrad) on small integer
+    operands, so every expected value is exact.  Row 0 / columns 0..3 of q_proj embed the case worked by hand in
+    tests/test_oracle_golden.py (LORA_KAT, literals); the rest is checked against plain numpy int64 sums written out here.
+    p = 0.5 (factor 2, exact): the keep mask is the library's counter-based one, read back through mh_dropout_bf16."""
+    from myriad_amd.lora import BORDER, V_TAG, LoraQV, lora_param_specs
+    from myriad_amd.myriad import ParamStore
+    from tests.test_oracle_golden import LORA_KAT as k
+    D, r, M, s = 128, 8, 4, 2
+    rng = np.random.default_rng(5)
+
+    def sparse(shape, lo, hi, dens):
+        return rng.integers(lo, hi + 1, shape) * (rng.random(shape) < dens)
+
+    x = sparse((M, D), -2, 2, 0.25)
+    W = sparse((3 * D, D), -1, 1, 0.2)
+    Aq, Av = sparse((r, D), -1, 1, 0.2), sparse((r, D), -1, 1, 0.2)
+    Bq, Bv = sparse((D, r), -1, 1, 0.3), sparse((D, r), -1, 1, 0.3)
+    dqkv = sparse((M, 3 * D), -1, 1, 0.2)
+    # the hand-worked 4 x 4, rank-2 case in row 0 of the batch, rows 0..3 of q_proj
+    x[:, :4] = 0; dqkv[:, :4] = 0                                  # rows 1.. stay out of the literal 4 x 4 gradients
+    x[0] = 0; x[0, :4] = k["x"]
+    W[:4] = 0; W[:4, :4] = k["W"]
+    Aq[:, :4] = 0; Aq[:2, :4] = k["A"]
+    Bq[:4] = 0; Bq[:4, :2] = k["B"]
+    dqkv[0] = 0; dqkv[0, :4] = k["dy"]
+    st = ParamStore(lora_param_specs(1, D, r), DEV)
+    lora = LoraQV(1, D, r, 16.0, p, st.p, st.g, DEV)
+    nAq, nAv, nBq, nBv = lora.names(0)
+    for n, a in ((nAq, Aq), (nAv, Av), (nBq, Bq), (nBv, Bv)):
+        st.p[n].copy_(torch.from_numpy(a).float())
+    layer = dict(wqkv=torch.from_numpy(W).to(DEV, torch.bfloat16), wqkvT=torch.from_numpy(W.T.copy()).to(DEV, torch.bfloat16))
+    lora.extend_weights(layer)
+    lora.refresh([layer])
+    lora.step_seed = 9
+    x_ext = lora.x_ext(0, M)
+    x_ext[:, :D].copy_(torch.from_numpy(x).to(DEV, torch.bfloat16))
+    p_eff, seed = lora.forward_border(0, x_ext, training=True)
+    assert p_eff == p
+    qkv = ops.gemm(x_ext, layer["wqkv_ext"], out_dtype=torch.float32).cpu().numpy()
+    if p > 0:
+        ones = torch.ones(M, D, dtype=torch.bfloat16, device=DEV)
+        mq = ops.dropout_bf16(ones, p, seed).float().cpu().numpy().astype(np.int64)
+        mv = ops.dropout_bf16(ones, p, seed ^ V_TAG).float().cpu().numpy().astype(np.int64)
+        assert set(np.unique(mq)) == {0, 2} and set(np.unique(mv)) == {0, 2} and (mq != mv).any()
+    else:
+        mq = mv = np.ones((M, D), np.int64)
+    tq, tv = (x * mq) @ Aq.T, (x * mv) @ Av.T                       # [M, r] int64
+    assert np.abs(s * tq).max() <= 256 and np.abs(s * tv).max() <= 256      # the border holds s*t in bf16: exact
+    want = x @ W.T
+    want[:, :D] += s * tq @ Bq.T
+    want[:, 2 * D:] += s * tv @ Bv.T
+    assert np.array_equal(qkv, want.astype(np.float32))
+    if p == 0:
+        assert qkv[0, :4].tolist() == k["y"]                        # the literal, hand-computed answer
+    # ---- backward
+    st.flat_g.zero_()
+    dq_t = torch.from_numpy(dqkv).to(DEV, torch.bfloat16)
+    dxn = lora.backward_from_dqkv(0, dq_t, layer["wqkvT_ext"], x_ext, p_eff, seed, defer_wgrad=False).cpu().numpy()
+    torch.cuda.synchronize()
+    dq, dv = dqkv[:, :D], dqkv[:, 2 * D:]
+    gq, gv = dq @ Bq, dv @ Bv                                       # [M, r]
+    want_dx = dqkv @ W + s * mq * (gq @ Aq) + s * mv * (gv @ Av)
+    assert np.array_equal(dxn, want_dx.astype(np.float32))
+    assert np.array_equal(st.g[nAq].cpu().numpy(), (s * gq.T @ (x * mq)).astype(np.float32))
+    assert np.array_equal(st.g[nAv].cpu().numpy(), (s * gv.T @ (x * mv)).astype(np.float32))
+    assert np.array_equal(st.g[nBq].cpu().numpy(), (s * dq.T @ tq).astype(np.float32))
+    assert np.array_equal(st.g[nBv].cpu().numpy(), (s * dv.T @ tv).astype(np.float32))
+    if p == 0:
+        assert dxn[0, :4].tolist() == k["dx"]
+        assert st.g[nAq][:2, :4].cpu().tolist() == k["dA"] and st.g[nBq][:4, :2].cpu().tolist() == k["dB"]

@@ -209,3 +209,48 @@ def test_lr_schedule_and_adamw():
     assert R.uses_weight_decay("VETokenizer.base_prompts", 2)
     assert not R.uses_weight_decay("VETokenizer.meta_net.15.bias", 1)
     assert not R.uses_weight_decay("ln_vision.weight", 1)
+
+
+def test_pipeline_chain_every_id_equals_the_reference():
+    """Full-pipeline peaked fixture (tools/make_golden.py case_pipeline_chain: the reference's ViT / Q-Former / networks /
+    LLaMA composed as myriad.py:241-272,433-454): the oracle's encode_img + prompt wrap + greedy loop reproduces every id,
+    at batch 4 and for row 3 alone."""
+    g = load("pipeline_chain")
+    sd = gu.pipeline_chain_weights(g["probe"])
+    image, maps, before, after = gu.pipeline_chain_batch()
+    ew = sd["llama_model.model.embed_tokens.weight"]
+    with torch.no_grad():
+        for name, sel in (("b4", [0, 1, 2, 3]), ("b1r3", [3])):
+            img = R.encode_img(sd, image[sel], maps[sel], 1, "myriad")
+            wrapped = torch.cat([ew[before[sel]], img, ew[after[sel]]], 1)
+            ids, margins = R.greedy_generate(sd, wrapped, 32, max_new_tokens=90, min_length=1, return_margins=True)
+            assert torch.equal(ids, g[name + "_ids"]), (name, ids, g[name + "_ids"])
+            close(margins, g[name + "_margins"], rtol=2e-3, atol=2e-3)
+
+
+# ---- a-14: known-answer vectors for peft's LoRA form, worked by hand (no peft, no oracle code in the expected values) ----
+#   x = [1 2 3 4]   W = [[1 0 2 0] [0 1 0 1] [1 1 0 0] [0 0 1 2]]   A (r=2) = [[1 0 1 0] [0 2 0 1]]   B = [[1 0] [0 1] [2 1] [1 3]]
+#   alpha = 4, r = 2 -> scale 2.   W x = [7 6 3 11];  A x = [4 8];  B (A x) = [4 8 16 28];  y = W x + 2 B A x = [15 22 35 67]
+#   dropout p = 0.5 keeping elements 0 and 2 (factors [2 0 2 0]): drop(x) = [2 0 6 0]; A drop(x) = [8 0]; B . = [8 0 16 8];
+#   y = [7 6 3 11] + 2 [8 0 16 8] = [23 6 35 27]
+#   backward (no dropout) with dy = [1 0 -1 2]:  B^T dy = [1 5];  dA = 2 [1 5]^T x = [[2 4 6 8] [10 20 30 40]];
+#   dB = 2 dy (A x)^T = [[8 16] [0 0] [-8 -16] [16 32]];  dx = W^T dy + 2 A^T B^T dy = [0 -1 4 4] + [2 20 2 10] = [2 19 6 14]
+LORA_KAT = dict(
+    x=[1., 2., 3., 4.], W=[[1., 0., 2., 0.], [0., 1., 0., 1.], [1., 1., 0., 0.], [0., 0., 1., 2.]],
+    A=[[1., 0., 1., 0.], [0., 2., 0., 1.]], B=[[1., 0.], [0., 1.], [2., 1.], [1., 3.]], alpha=4.0, r=2,
+    y=[15., 22., 35., 67.], keep=[2., 0., 2., 0.], y_drop=[23., 6., 35., 27.], dy=[1., 0., -1., 2.],
+    dA=[[2., 4., 6., 8.], [10., 20., 30., 40.]], dB=[[8., 16.], [0., 0.], [-8., -16.], [16., 32.]], dx=[2., 19., 6., 14.])
+
+
+def test_peft_lora_formula_known_answer():
+    k = LORA_KAT
+    x = torch.tensor([k["x"]], requires_grad=True)
+    W = torch.tensor(k["W"])
+    A = torch.tensor(k["A"], requires_grad=True)
+    Bm = torch.tensor(k["B"], requires_grad=True)
+    y = R.lora_linear(x, W, A, Bm, k["alpha"], k["r"])
+    assert y.tolist() == [k["y"]]
+    y.backward(torch.tensor([k["dy"]]))
+    assert A.grad.tolist() == k["dA"] and Bm.grad.tolist() == k["dB"] and x.grad.tolist() == [k["dx"]]
+    y2 = R.lora_linear(x.detach(), W, A.detach(), Bm.detach(), k["alpha"], k["r"], torch.tensor([k["keep"]]))
+    assert y2.tolist() == [k["y_drop"]]

@@ -477,6 +477,90 @@ def case_composite(M):
     save("composite_fullwidth", **res)
 
 
+def _ref_pipeline(M, sd, V):
+    """The reference's own modules wired as myriad.py:241-272 (encode_img) and :354-375 (prompt_wrap), full width, reduced
+    depth.  Returns (wrap(image, maps, before, after, stage) -> inputs_embeds without BOS, lm)."""
+    N = M["networks"]
+    vit = ref_vit(M, 1408, 1, 16, 4.3637, 224)
+    load_sd(vit, sd, "visual_encoder.")
+    qf = ref_qformer(M, 768, 2, 12, 3072, 1408, 32)
+    load_sd(qf.bert, sd, "Qformer.bert.")
+    lm = ref_llama(M, 4096, 1, 32, 11008, V)
+    load_sd(lm, sd, "llama_model.")
+    ad = N.LoraAdaptorV2(dims=1408, input_dim=4)
+    load_sd(ad, sd, "expert_adaptor.")
+    ins = N.VEInstructorV2()
+    load_sd(ins, sd, "VEInstructor.")
+    tok = N.VETokenizer()
+    load_sd(tok, sd, "VETokenizer.")
+    lnv = nn.LayerNorm(1408)
+    lnv.load_state_dict({"weight": sd["ln_vision.weight"], "bias": sd["ln_vision.bias"]})
+    proj = nn.Linear(768, 4096)
+    proj.load_state_dict({"weight": sd["llama_proj.weight"], "bias": sd["llama_proj.bias"]})
+    qtok = sd["query_tokens"]
+
+    def wrap(image, maps, before, after, stage=1):
+        B = image.shape[0]
+        x = lnv(ad(vit(image)).float())
+        q = qtok.expand(B, -1, -1)
+        if stage in (1, 2):
+            q = torch.cat([q, ins(maps)], 1)
+        qo = qf.bert(query_embeds=q, encoder_hidden_states=x, encoder_attention_mask=torch.ones(B, 257, dtype=torch.long),
+                     return_dict=True).last_hidden_state
+        img = proj(qo)
+        if stage in (0, 1):
+            img = torch.cat([img, tok(maps)], 1)
+        embed = lm.model.embed_tokens
+        return torch.cat([embed(before), img, embed(after)], 1)
+
+    return wrap, lm
+
+
+def case_pipeline_chain(M):
+    """Peaked FULL-PIPELINE greedy fixture (tests/golden_utils.py: PIPELINE_CHAIN): every id of `Myriad.generate`
+    (myriad.py:433-454, stage-1 layout) at batch 4 and batch 1, the first id picked by the image."""
+    c = gu.PIPELINE_CHAIN
+    V = c["vocab"]
+    image, maps, before, after = gu.pipeline_chain_batch()
+    rows = ("row0", "row1", "row2", "row3")
+    with torch.no_grad():
+        wrap, lm = _ref_pipeline(M, gu.pipeline_chain_weights(None), V)
+        emb = wrap(image, maps, before, after)
+        S = emb.shape[1]
+        assert S == 4 + 81 + 18 + 28, S
+        H = lm.model(inputs_embeds=emb, attention_mask=torch.ones(4, S, dtype=torch.long), return_dict=True).last_hidden_state[:, -1]
+        Hn = H / H.norm(dim=1, keepdim=True)
+        print("cosine between the rows' final hidden states:\n", (Hn @ Hn.T).numpy().round(4))
+        probe = c["gamma"] * torch.linalg.pinv(H.double()).T.float()            # [4, 4096]: probe_i . H_j = gamma * delta_ij
+        print("probe row norms", probe.norm(dim=1).tolist(), " |h|", H.norm(dim=1).tolist())
+        res = dict(probe=probe)
+        for variant in ("fp32", "bf16w"):
+            sd = gu.pipeline_chain_weights(probe)
+            if variant == "bf16w":     # robustness probe: every matrix rounded to bf16, as the HIP path stores them
+                sd = {k: (v.bfloat16().float() if v.ndim >= 2 else v) for k, v in sd.items()}
+            wrap, lm = _ref_pipeline(M, sd, V)
+            for name, sel in (("b4", [0, 1, 2, 3]), ("b1", [0]), ("b1r3", [3])):
+                _ref_greedy.pmax = []
+                e = wrap(image[sel], maps[sel], before[sel], after[sel])
+                ids, margins = _ref_greedy(lm, e, 90)
+                pmax = torch.stack(_ref_greedy.pmax, 1)
+                live = torch.cat([torch.ones(ids.shape[0], 1, dtype=torch.bool), (ids[:, :-1] == 2).cumsum(1) == 0], 1)
+                print(variant, name, "steps", ids.shape[1], "min margin", float(margins[live].min()), "min pmax", float(pmax[live].min()))
+                assert float(margins[live].min()) >= 2.0 and float(pmax[live].min()) >= 0.5
+                for i, r in enumerate(sel):
+                    want = gu.PIPELINE_CHAINS[rows[r]]
+                    got = ids[i].tolist()
+                    n = min(len(want), len(got))
+                    assert got[:n] == want[:n], (variant, name, r, got, want)
+                if variant == "fp32":
+                    res[name + "_ids"], res[name + "_margins"], res[name + "_pmax"] = ids, margins, pmax
+                else:
+                    assert torch.equal(ids, res[name + "_ids"]), (name, ids, res[name + "_ids"])
+    assert res["b4_ids"].shape[1] == 33 and res["b4_ids"][0, -2:].tolist() == [2277, 29937]
+    assert res["b1r3_ids"].shape[1] == 3 and res["b1r3_ids"][0, -1] == 835       # alone in the batch, row 3 IS row 0: [835] stops it
+    save("pipeline_chain", **res)
+
+
 def case_optim(M):
     O = M["optims"]
 
@@ -521,7 +605,7 @@ def case_optim(M):
 
 CASES = dict(vit=case_vit, networks=case_networks, networks_bf16=case_networks_bf16, qformer=case_qformer, llama=case_llama, decode_chain=case_decode_chain,
              clamp_ce=case_clamp_ce,
-             composite=case_composite, optim=case_optim)
+             composite=case_composite, pipeline_chain=case_pipeline_chain, optim=case_optim)
 
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()

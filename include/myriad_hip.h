@@ -261,13 +261,30 @@ int mh_adamw_step(float* p, const float* g, float* m, float* v, void* shadow_bf1
 /* K18 data path: NSA / CutPaste self-supervised anomaly augmentation on uint8 crops resident in HBM --
    minigpt4/datasets/self_sup_tasks.py:254-268 (the 'swap' and 'uniform' blends) and :97-113 (the label).  The random patch
    geometry is sampled on the host exactly as the reference samples it (myriad_amd/self_sup.py); ops is a device array of
-   48-byte records {int image, y0, x0, h, w, sy, sx, mode (0 swap / 1 uniform); long mask_off; double factor}, masks the
-   byte pool the records index, hs / ws HOST copies of h, w.  out starts as a copy of dest; union_mask [B,H,W] u8 zeroed.
+   56-byte records {int image, y0, x0, h, w, sy, sx, mode; long mask_off; double factor; long patch_off} -- mode & 3: 0 swap,
+   1 uniform, 2 union mask only (a Poisson patch); mode & 4: the source pixels are the resampled patch [h][w][3] at patch_off
+   of `patches` (may be NULL when no record sets the bit) -- masks the byte pool the records index, hs / ws HOST copies of
+   h, w.  out starts as a copy of dest; union_mask [B,H,W] u8 zeroed.
    mh_patch_label: mode 0 binary, 1 continuous (factor [B] f64), 2 intensity, 3 logistic-intensity (k, x0). */
 int mh_patch_blend_u8(void* out, const void* src, const void* masks, const void* ops, const int* hs, const int* ws,
-                      int n_ops, int B, int H, int W, void* union_mask, mh_stream_t s);
+                      int n_ops, int B, int H, int W, void* union_mask, const void* patches, mh_stream_t s);
 int mh_patch_label(const void* dest, const void* out, const void* union_mask, void* sums_ws, void* lm_ws, float* label,
                    const double* factor, int B, int H, int W, int mode, int tol, double k, double x0, mh_stream_t s);
+/* The two OpenCV steps of the shipped augmentation recipe (self_sup_tasks.py:213-227 cv2.resize, :269-288 cv2.seamlessClone
+   with NORMAL_CLONE; anomaly_detection.py:118-141), from their published algorithms -- PARITY UNPINNED, OpenCV is absent.
+   mh_patch_resize_u8: 8-bit INTER_LINEAR of the box (sy, sx, sh, sw) of src[image] to out [h][w][3]; xi / yi [w] / [h] left
+   source indices, xw / yw [w][2] / [h][2] 11-bit weights (device ints; myriad_amd/self_sup.linear_resize_tables); an exact
+   2 x 2 decimation is the rounded mean of 4 (tables may be NULL).
+   mh_patch_poisson_u8: gradient-domain cloning of patch [hp][wp][3] into out[image] in place.  pms [hp][wp] the clone mask
+   (border cleared), eroded [h][w] its ROI after erode(3x3) x 3, ROI h x w at (y0s, x0s) of the patch and (dy0, dx0) of the
+   image; Sh [h-2][h-2], Sw [w-2][w-2] sine matrices, cy / cx their 2 cos terms (f64); ws mh_patch_poisson_ws_doubles(h, w)
+   doubles.  float64 throughout, interior = floor(clamp(u, 0, 255) + 1e-6). */
+int mh_patch_resize_u8(const void* src, int image, int H, int W, int sy, int sx, int sh, int sw, const int* xi, const int* xw,
+                       const int* yi, const int* yw, void* out, int h, int w, mh_stream_t s);
+long mh_patch_poisson_ws_doubles(int h, int w);
+int mh_patch_poisson_u8(void* out, int image, int H, int W, const void* patch, int hp, int wp, const void* pms,
+                        const void* eroded, int y0s, int x0s, int dy0, int dx0, int h, int w, const double* Sh, const double* cy,
+                        const double* Sw, const double* cx, double* ws, mh_stream_t s);
 
 /* Gated AdamW: torch.optim.AdamW skips parameters whose .grad is None -- a module no rank used this step (random prompt
    stage, myriad.py:378; DDP find_unused_parameters, runner_base.py:96-98) keeps its parameters, moments and step count.

@@ -43,7 +43,10 @@ __device__ __forceinline__ int swz_src_chunk(int row, int phys) {
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N == 0 || N == 3 || N == 4 || N == 6 || N == 8 || N == 12 || N == 16, "unsupported count");
+  static_assert(N == 0 || N == 3 || N == 4 || N == 6 || N == 8 || N == 12 || N == 16 || N == 18 || N == 24 || N == 32, "unsupported count");
+  if (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+  if (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+  if (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
   if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -158,7 +161,9 @@ __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void gemm_nt_kernel(const b
       // loads issued after tile t's own: LPT * (tiles in flight behind it)
       const int issued = (t + NST - 1) < nt ? (t + NST - 1) : nt;
       const int behind = issued - (t + 1);
-      if (NST >= 4 && behind >= 2) wait_vmcnt<2 * LPT>();
+      if (NST >= 6 && behind >= 4) wait_vmcnt<4 * LPT>();
+      else if (NST >= 5 && behind >= 3) wait_vmcnt<3 * LPT>();
+      else if (NST >= 4 && behind >= 2) wait_vmcnt<2 * LPT>();
       else if (NST >= 3 && behind >= 1) wait_vmcnt<LPT>();
       else wait_vmcnt<0>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -294,6 +299,8 @@ static int dispatch(const GemmArgs& g, hipStream_t stream) {
     case 8: return launch_gemm<0, 4, 128, 2, 32>(g, stream);   // BK=32: 64 KiB, 2 blocks/CU, 3 tiles in flight
     case 9: return launch_gemm<0, 2, 128, 2, 64, 8>(g, stream);   // 8 waves/block (wave tile 32x64), 2 blocks/CU
     case 10: return launch_gemm<0, 4, 128, 1, 64, 8>(g, stream);  // 8 waves/block, 4-deep ring, 1 block/CU
+    case 13: return launch_gemm<0, 6, 64, 1>(g, stream);          // 128x64, 6-deep ring (144 KiB): 5 K tiles in flight, 1 block/CU
+    case 14: return launch_gemm<0, 5, 64, 1>(g, stream);          // 128x64, 5-deep ring (120 KiB)
     case 12:                                                      // 256x256x32, 4-deep ring (gemm_256.hip), 1 block/CU
       return mh_launch_gemm_256(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, g.bias, g.residual, g.ldr, g.flags,
                                 g.alpha, g.splits, g.tps, g.split_stride, stream);
@@ -513,7 +520,11 @@ static int auto_splits(int M, int N, int K) {
 }
 
 // 8-wave kernels run one workgroup per CU: pick the split count that best fills whole rounds of 256 workgroups
+static int g_force_big_splits = 0;
+extern "C" void mhdbg_set_big_splits(int s) { g_force_big_splits = s; }   // debug hook (sweep tools), not part of the ABI
+
 static int big_tile_splits(int M, int N, int K, int tile_n) {
+  if (g_force_big_splits > 0) return g_force_big_splits;
   const long tiles = (long)((M + 255) / 256) * ((N + tile_n - 1) / tile_n);
   const int kt = K / 64;
   int best = 1;
@@ -559,7 +570,9 @@ static void gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits) 
     if (s > 1 && (size_t)s * M * N * sizeof(float) <= g_ws_bytes) *splits = s;
   }
   const long t128 = (long)((M + BM - 1) / BM) * ((N + 127) / 128);
-  if (t128 * *splits < 160) *kernel = 3;
+  // < 256: the 128x128 grid would not give every CU a workgroup (round 3, tools/gemm_small_sweep.py: 2056x1408x1408, 187
+  // tiles, 22.0 -> 17.9 us; 648x4096x768 15.1 -> 12.7 us; the bound was 160 before)
+  if (t128 * *splits < 256) *kernel = 3;
 }
 
 extern "C" int mh_gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits) {

@@ -113,7 +113,10 @@ class AnomalyDetectionDataset(Dataset):
     DatasetName = "AnomalyDetection"
 
     def __init__(self, vis_root: str, ann_paths: List[str], img_size: int = 224, crop_size: int = 224, stage: str = "train",
-                 self_sup_mode: str = "swap", seed: Optional[int] = None):
+                 self_sup_mode: Optional[str] = None, seed: Optional[int] = None):
+        """self_sup_mode None = the reference's recipe (anomaly_detection.py:118-141,254-264): per-class arguments, the patch
+        resampled (`resize=True`) and blended with cv2.NORMAL_CLONE.  'swap' / 'uniform' are explicit opt-outs that keep the
+        same geometry arguments but paste arithmetically without resampling (bit-pinned to the reference, no OpenCV step)."""
         self.vis_root, self.ann_paths, self.stage = vis_root, list(ann_paths), stage
         self.img_size, self.crop_size = img_size, crop_size
         self.annotation = []
@@ -125,6 +128,12 @@ class AnomalyDetectionDataset(Dataset):
 
     def __len__(self):
         return len(self.annotation)
+
+    def get_class_name(self, index):
+        """anomaly_detection.py:224-230: 'mvtec' when the first annotation file's name contains MVTEC, else 'visa'; the class
+        is the second path component of the image."""
+        ds = "mvtec" if "MVTEC" in self.ann_paths[0] else "visa"
+        return ds, self.annotation[index]["img_path"].split("/")[1]
 
     def _crop(self, index) -> np.ndarray:
         from PIL import Image
@@ -154,9 +163,15 @@ class AnomalyDetectionDataset(Dataset):
             while src_index == index and len(self) > 1:
                 src_index = int(self.rng.randint(len(self)))
             src = self._crop(src_index)
-            aug, mask, boxes = self_sup.patch_ex(image, src, mode=self.self_sup_mode, rng=self.rng, **self_sup.NSA_ARGS)
-            while mask.sum() == 0:
-                aug, mask, boxes = self_sup.patch_ex(image, src, mode=self.self_sup_mode, rng=self.rng, **self_sup.NSA_ARGS)
+            ds, class_name = self.get_class_name(index)
+            args = self_sup.self_sup_args(ds, class_name)
+            if args.get("width_bounds_pct") is None or args.get("intensity_logistic_params") is None:
+                raise KeyError(f"MVTec class {class_name!r} is in neither argument table (the reference fails on the None it looks up)")
+            if self.self_sup_mode is not None:
+                args.update(mode=self.self_sup_mode, resize=False)
+            aug, mask, boxes = self_sup.patch_ex(image, src, rng=self.rng, **args)
+            while mask.sum() == 0:                      # anomaly_detection.py:263-265
+                aug, mask, boxes = self_sup.patch_ex(image, src, rng=self.rng, **args)
             ret["aug_image"] = self._to_tensor(aug)
             aug_anom = bool(mask.sum() != 0)
         ret.update(sample_strings(aug_anom))
@@ -169,7 +184,7 @@ def _build_anomaly_detection(cfg, split):
     root = info.get("vis_root", info.get("storage", "./data"))
     return AnomalyDetectionDataset(root, info.get("ann_paths", []), stage="train" if split == "train" else "test",
                                    img_size=int(cfg.get("img_size", 224)), crop_size=int(cfg.get("crop_size", 224)),
-                                   self_sup_mode=cfg.get("self_sup_mode", "swap"))
+                                   self_sup_mode=cfg.get("self_sup_mode", None))
 
 
 def collate(batch: List[dict]) -> dict:

@@ -1,11 +1,18 @@
 """ORACLE (test infrastructure, never on the product path): CPU restatement of the reference's NSA / CutPaste
-self-supervised augmentation `patch_ex` / `_patch_ex` (minigpt4/datasets/self_sup_tasks.py:11-292) for the branches that
-need neither cv2.resize nor cv2.seamlessClone.
+self-supervised augmentation `patch_ex` / `_patch_ex` (minigpt4/datasets/self_sup_tasks.py:11-292), every branch.
 
-Pinned against tests/golden/self_sup.npz, produced by the reference's own function (tools/make_golden_selfsup.py, scipy
-shims for cv2.medianBlur / skimage.filters.median).  np.random is consumed in exactly the reference's order, so with the same
-seed the same patches are drawn.  Parity UNPINNED (neither cv2 nor the reference's dependency can run here): `resize=True`
-(cv2.resize, bilinear) and the Poisson modes (cv2.seamlessClone) -- both raise here.
+Pinned against tests/golden/self_sup.npz, produced by the reference's own function (tools/make_golden_selfsup.py).
+np.random is consumed in exactly the reference's order, so with the same seed the same patches are drawn.
+What the golden pins, and what it cannot:
+  * arithmetic blends ('swap', 'uniform'), patch geometry, object masks, labels: the reference ran with scipy stand-ins
+    for cv2.medianBlur / skimage.filters.median only -- PINNED;
+  * `resize=True` and `mode=cv2.NORMAL_CLONE` (the shipped recipe, anomaly_detection.py:118-141): the reference's own code
+    around the two OpenCV calls (size draws and clipping :213-224, mask scaling / border / centre / the 50-pixel rule
+    :271-279) is PINNED -- the reference ran, with `cv2.resize` and `cv2.seamlessClone` supplied by `resize_linear_u8` and
+    `seamless_clone` below.  Those two functions restate OpenCV's published algorithms (modules/imgproc/src/resize.cpp:
+    8-bit INTER_LINEAR with 11-bit fixed-point coefficients; modules/photo/src/seamless_cloning*.cpp: gradient-domain
+    NORMAL_CLONE solved with a discrete sine transform) and are **PARITY UNPINNED**: OpenCV is not installed, is pinned to no
+    version anywhere in the reference tree, and no vector of its output exists here.
 """
 from __future__ import annotations
 
@@ -27,15 +34,16 @@ def patch_ex(ima_dest, ima_src=None, same=False, num_patches=1, mode="swap", wid
              min_object_pct=0.25, min_overlap_pct=0.25, shift=True, label_mode="binary", skip_background=None, tol=1,
              resize=False, gamma_params=None, intensity_logistic_params=(1 / 6, 20), resize_bounds=(0.7, 1.3),
              num_ellipses=None, cutpaste_patch_generation=False):
-    """self_sup_tasks.py:11-113.  Returns (patchex uint8, label, label_boxes)."""
-    if mode not in ("swap", "uniform"):
-        raise NotImplementedError("Poisson blending (cv2.seamlessClone) cannot be restated or pinned without OpenCV")
+    """self_sup_tasks.py:11-113.  Returns (patchex uint8, label, label_boxes).  mode: 'swap', 'uniform', or
+    NORMAL_CLONE (= cv2.NORMAL_CLONE = 1, also spelled 'normal_clone')."""
+    if mode == "normal_clone":
+        mode = NORMAL_CLONE
+    if mode not in ("swap", "uniform", NORMAL_CLONE):
+        raise NotImplementedError("MIXED_CLONE / 'mix' are not restated (no shipped recipe selects them)")
     if cutpaste_patch_generation:                                   # :47-54
         width_bounds_pct, resize, skip_background = None, False, None
         min_overlap_pct = min_object_pct = gamma_params = None
         num_patches = 1
-    if resize:
-        raise NotImplementedError("resize=True needs cv2.resize; unpinned")
     ima_src = ima_dest.copy() if same or ima_src is None else ima_src   # :56
     src_obj = dest_obj = None
     if skip_background is not None and not cutpaste_patch_generation:   # :58-68
@@ -57,7 +65,7 @@ def patch_ex(ima_dest, ima_src=None, same=False, num_patches=1, mode="swap", wid
         if i == 0 or np.random.randint(2) > 0:
             patchex, ((a1, b1), (a2, b2)), pm = _patch_ex(patchex, ima_src, dest_obj, src_obj, mode, shift, width_bounds_pct,
                                                           gamma_params, min_object_pct, min_overlap_pct, factor, num_ellipses,
-                                                          cutpaste_patch_generation)
+                                                          cutpaste_patch_generation, resize, resize_bounds)
             if pm is not None:
                 mask[a1:b1, a2:b2] = pm
                 c1lo, c1hi, c2lo, c2hi = min(c1lo, a1), max(c1hi, b1), min(c2lo, a2), max(c2hi, b2)
@@ -81,8 +89,8 @@ def patch_ex(ima_dest, ima_src=None, same=False, num_patches=1, mode="swap", wid
 
 
 def _patch_ex(ima_dest, ima_src, dest_obj, src_obj, mode, shift, width_bounds_pct, gamma_params, min_object_pct,
-              min_overlap_pct, factor, num_ellipses, cutpaste):
-    """self_sup_tasks.py:116-292 (resize=False, arithmetic blends)."""
+              min_overlap_pct, factor, num_ellipses, cutpaste, resize=False, resize_bounds=(0.7, 1.3)):
+    """self_sup_tasks.py:116-292."""
     dims = np.array(ima_dest.shape)
     if cutpaste:                                                    # :118-146
         skip_bg = False
@@ -147,9 +155,18 @@ def _patch_ex(ima_dest, ima_src, dest_obj, src_obj, mode, shift, width_bounds_pc
                 return ima_dest.copy(), ((0, 0), (0, 0)), None
     src = ima_src[a1:b1, a2:b2]                                     # :211-212
     height, width, _ = src.shape
+    if resize:                                                      # :213-224
+        lb, ub = resize_bounds
+        scale = np.clip(np.random.normal(1, 0.5), lb, ub)
+        new_h = np.clip(scale * height, lo1, hi1)
+        new_w = np.clip(int(new_h / height * width), lo2, hi2)
+        new_h = np.clip(int(new_w / width * height), lo1, hi1)      # in case there was clipping
+        src = resize_linear_u8(src, (new_w, new_h))
+        height, width, _ = src.shape
+        pm = resize_linear_u8(pm[..., 0], (width, height))[..., None]
     so = None
-    if skip_bg:                                                     # :225-227 (cv2.resize to the same size: identity)
-        so = src_obj[a1:b1, a2:b2, 0].copy()[..., None]
+    if skip_bg:                                                     # :225-227
+        so = resize_linear_u8(src_obj[a1:b1, a2:b2, 0], (width, height))[..., None]
     if shift:                                                       # :230-252
         attempts = 0
         while True:
@@ -169,7 +186,21 @@ def _patch_ex(ima_dest, ima_src, dest_obj, src_obj, mode, shift, width_bounds_pc
                 return ima_dest.copy(), ((0, 0), (0, 0)), None
     if skip_bg:                                                     # :255-256
         pm = pm & (so | dest_obj[a1:b1, a2:b2])
-    if mode == "swap":                                              # :258-262 (uint8 arithmetic, wraps like numpy's)
+    if mode == NORMAL_CLONE:                                        # :269-288 Poisson interpolation
+        int_factor = np.uint8(np.ceil(factor * 255))
+        if skip_bg:                                                 # background added to the mask to avoid artefacts
+            pms = int_factor * (pm | ((1 - so) & (1 - dest_obj[a1:b1, a2:b2])))
+        else:
+            pms = int_factor * pm
+        pms[0], pms[-1], pms[:, 0], pms[:, -1] = 0, 0, 0, 0         # zero border
+        center = (b2 - (b2 - a2) // 2, a1 + (b1 - a1) // 2)         # (x, y)
+        if np.sum(pms > 0) < 50:
+            return ima_dest.copy(), ((0, 0), (0, 0)), None
+        try:
+            out = seamless_clone(src, ima_dest, pms, center, NORMAL_CLONE)
+        except ValueError:                                          # cv2.error in the reference
+            return ima_dest.copy(), ((0, 0), (0, 0)), None
+    elif mode == "swap":                                            # :258-262 (uint8 arithmetic, wraps like numpy's)
         out = ima_dest.copy()
         before = out[a1:b1, a2:b2]
         out[a1:b1, a2:b2] -= pm * before
@@ -181,3 +212,135 @@ def _patch_ex(ima_dest, ima_src, dest_obj, src_obj, mode, shift, width_bounds_pc
         out[a1:b1, a2:b2] += factor * pm * src
         out = np.uint8(np.floor(out))
     return out, ((a1, b1), (a2, b2)), pm
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# OpenCV stand-ins (PARITY UNPINNED, see the module docstring)
+# ---------------------------------------------------------------------------------------------------------------------
+NORMAL_CLONE, MIXED_CLONE = 1, 2
+
+
+def _linear_coeffs(ssize: int, dsize: int):
+    """resize.cpp (INTER_LINEAR, 8U): per destination index the left source index and the two 11-bit weights."""
+    scale = 1.0 / (float(dsize) / float(ssize))
+    idx = np.zeros(dsize, np.int64)
+    w = np.zeros((dsize, 2), np.int64)
+    for d in range(dsize):
+        f = np.float32((d + 0.5) * scale - 0.5)
+        sx = int(np.floor(f))
+        f = np.float32(f - np.float32(sx))
+        if sx < 0:
+            f, sx = np.float32(0), 0
+        if sx >= ssize - 1:
+            f, sx = np.float32(0), ssize - 1
+        idx[d] = sx
+        w[d, 0] = int(np.rint(np.float32(np.float32(1) - f) * np.float32(2048)))      # cvRound: half to even
+        w[d, 1] = int(np.rint(f * np.float32(2048)))
+    return idx, w
+
+
+def resize_linear_u8(img: np.ndarray, dsize) -> np.ndarray:
+    """cv2.resize(img, (width, height)) for uint8, default INTER_LINEAR (self_sup_tasks.py:219-227).  Horizontal pass in
+    int32 (pixel x 11-bit weight), vertical pass  ((b0 (S0 >> 4)) >> 16) + ((b1 (S1 >> 4)) >> 16) + 2) >> 2;  an exact 2 x 2
+    down-scale is the 2x2 mean, rounded (resize.cpp hands that case to INTER_AREA)."""
+    dw, dh = int(dsize[0]), int(dsize[1])
+    a = img if img.ndim == 3 else img[..., None]
+    sh, sw, c = a.shape
+    if (dw, dh) == (sw, sh):
+        return img.copy()
+    if sw == 2 * dw and sh == 2 * dh:
+        q = a.astype(np.int64)
+        out = ((q[0::2, 0::2] + q[0::2, 1::2] + q[1::2, 0::2] + q[1::2, 1::2] + 2) >> 2).astype(np.uint8)
+        return out if img.ndim == 3 else out[..., 0]
+    xi, xw = _linear_coeffs(sw, dw)
+    yi, yw = _linear_coeffs(sh, dh)
+    q = a.astype(np.int64)
+    x1 = np.minimum(xi + 1, sw - 1)
+    rows = q[:, xi, :] * xw[None, :, 0, None] + q[:, x1, :] * xw[None, :, 1, None]          # [sh, dw, c]
+    y1 = np.minimum(yi + 1, sh - 1)
+    s0, s1 = rows[yi], rows[y1]
+    out = ((((yw[:, 0, None, None] * (s0 >> 4)) >> 16) + ((yw[:, 1, None, None] * (s1 >> 4)) >> 16) + 2) >> 2)
+    out = np.clip(out, 0, 255).astype(np.uint8)
+    return out if img.ndim == 3 else out[..., 0]
+
+
+def _sine_matrix(n: int) -> np.ndarray:
+    k = np.arange(1, n + 1, dtype=np.float64)
+    return np.sin(np.pi * np.outer(k, k) / (n + 1))
+
+
+def poisson_dirichlet(rhs: np.ndarray, h: int, w: int) -> np.ndarray:
+    """Solve  u(y,x-1) + u(y,x+1) + u(y-1,x) + u(y+1,x) - 4 u(y,x) = rhs  on the (h-2) x (w-2) interior with zero boundary,
+    by the discrete sine transform (Cloning::solve: divide by 2 cos(pi (i+1)/(w-1)) + 2 cos(pi (j+1)/(h-1)) - 4)."""
+    nh, nw = h - 2, w - 2
+    Sh, Sw = _sine_matrix(nh), _sine_matrix(nw)
+    t = Sh @ rhs @ Sw
+    den = (2.0 * np.cos(np.pi * np.arange(1, nh + 1) / (nh + 1)))[:, None] + (2.0 * np.cos(np.pi * np.arange(1, nw + 1) / (nw + 1)))[None, :] - 4.0
+    return (Sh @ (t / den) @ Sw) * (2.0 / (nh + 1)) * (2.0 / (nw + 1))
+
+
+TRUNC_EPS = 1e-6    # OpenCV truncates (static_cast<uchar>); a solution that is an exact integer must not fall to the level below
+                    # through 1e-12 of round-off -- every implementation here adds this before truncating (stated in DESIGN.md)
+
+
+def seamless_clone(src: np.ndarray, dst: np.ndarray, mask: np.ndarray, center, flags: int = NORMAL_CLONE) -> np.ndarray:
+    """cv2.seamlessClone(src, dst, mask, (x, y), cv2.NORMAL_CLONE) for uint8 3-channel images, float64 arithmetic.
+    seamless_cloning.cpp: the mask's 1-pixel border is cleared; roi_s = bounding box of the non-zero mask; roi_d = the same
+    size around `center`; seamless_cloning_impl.cpp (normalClone): forward-difference gradients of the destination ROI and
+    of the masked source ROI, mixed with the mask eroded 3 x (3 x 3, border never erodes), divergence, minus the Laplacian
+    of the ROI's boundary ring, Poisson solve with that ring as Dirichlet data, clamp to [0, 255] and truncate."""
+    if flags != NORMAL_CLONE:
+        raise NotImplementedError("only NORMAL_CLONE (the shipped recipe) is restated")
+    m = np.array(mask, copy=True)
+    if m.ndim == 3:
+        m = m[..., 0]
+    m[0, :] = m[-1, :] = 0
+    m[:, 0] = m[:, -1] = 0
+    ys, xs = np.nonzero(m)
+    out = dst.copy()
+    if ys.size == 0:
+        return out
+    y0, y1, x0, x1 = ys.min(), ys.max() + 1, xs.min(), xs.max() + 1
+    h, w = y1 - y0, x1 - x0
+    dx0, dy0 = int(center[0]) - w // 2, int(center[1]) - h // 2
+    if dx0 < 0 or dy0 < 0 or dx0 + w > dst.shape[1] or dy0 + h > dst.shape[0]:
+        raise ValueError("seamless_clone: the destination ROI leaves the image (OpenCV raises cv2.error)")
+    if h < 3 or w < 3:
+        return out
+    mroi = m[y0:y1, x0:x1] != 0
+    D = dst[dy0:dy0 + h, dx0:dx0 + w].astype(np.float64)
+    P = np.where(mroi[..., None], src[y0:y1, x0:x1], 0).astype(np.float64)
+    me = m[y0:y1, x0:x1].astype(np.int64)
+    for _ in range(3):                                                # erode(3 x 3) x 3; outside the ROI counts as the maximum
+        me = ndi.minimum_filter(me, size=3, mode="constant", cval=255)
+    mf = (me / 255.0)[..., None]                                      # binaryMaskFloat
+    mi = ((255 - me) / 255.0)[..., None]                              # bitwise_not, then / 255
+
+    def grad_x(a):                                                    # filter2D [0, -1, 1], BORDER_REFLECT_101
+        g = np.empty_like(a)
+        g[:, :-1] = a[:, 1:] - a[:, :-1]
+        g[:, -1] = a[:, -2] - a[:, -1]
+        return g
+
+    def grad_y(a):
+        g = np.empty_like(a)
+        g[:-1] = a[1:] - a[:-1]
+        g[-1] = a[-2] - a[-1]
+        return g
+
+    gx = grad_x(D) * mi + grad_x(P) * mf
+    gy = grad_y(D) * mi + grad_y(P) * mf
+    lap = np.zeros_like(D)                                            # filter2D [-1, 1, 0]: g(x) - g(x-1), interior only is used
+    lap[:, 1:] += gx[:, 1:] - gx[:, :-1]
+    lap[1:, :] += gy[1:, :] - gy[:-1, :]
+    ring = D.copy()
+    ring[1:-1, 1:-1] = 0
+    ring_lap = np.zeros_like(D)                                       # Laplacian(bound): 4-neighbour stencil
+    ring_lap[1:-1, 1:-1] = (ring[1:-1, :-2] + ring[1:-1, 2:] + ring[:-2, 1:-1] + ring[2:, 1:-1] - 4 * ring[1:-1, 1:-1])
+    rhs = (lap - ring_lap)[1:-1, 1:-1]
+    res = D.copy()
+    for ch in range(D.shape[2]):
+        u = poisson_dirichlet(rhs[..., ch], h, w)
+        res[1:-1, 1:-1, ch] = np.floor(np.clip(u, 0.0, 255.0) + TRUNC_EPS)
+    out[dy0:dy0 + h, dx0:dx0 + w] = np.clip(res, 0, 255).astype(np.uint8)
+    return out

@@ -42,13 +42,15 @@ def test_product_host_path_matches_the_oracle(name, seed, kw):
     assert np.array_equal(np.asarray(boxes, np.int64).reshape(-1, 4), G[name + "_boxes"])
     np.testing.assert_allclose(np.asarray(label, np.float64), G[name + "_label"], rtol=0, atol=1e-12)
     with pytest.raises(NotImplementedError):
-        P.patch_ex(dest, src, mode="poisson")
+        P.patch_ex(dest, src, mode="mix")
 
 
 @pytest.mark.gpu
 def test_device_blend_and_label_match_the_oracle():
     """csrc/selfsup.hip on a batch of crops in HBM: bit-exact uint8 images, labels within fp32 rounding of the float64 oracle,
-    for every blend / label mode of the golden cases (one batch per label mode: the label kernel takes one mode per launch)."""
+    for every case of the golden -- the arithmetic blends, the resampled patches (8-bit fixed-point bilinear) and the Poisson
+    clones of the shipped recipe (float64 sine-transform solve on the device; the truncation sees the same values as the
+    oracle's) -- one batch per label mode (the label kernel takes one mode per launch)."""
     ex = P.PatchExHIP("cuda")
     by_mode = {}
     for name, seed, kw in MK.CASES:
@@ -69,3 +71,96 @@ def test_device_blend_and_label_match_the_oracle():
         for i, (name, seed, kw) in enumerate(cases):
             assert np.array_equal(out[i].cpu().numpy(), G[name + "_patchex"]), name
             np.testing.assert_allclose(label[i].cpu().numpy().astype(np.float64), G[name + "_label"][..., 0], rtol=0, atol=2e-5, err_msg=name)
+
+
+# ---- properties of the two restated OpenCV algorithms (their pixels are PARITY UNPINNED: OpenCV is absent) ----------------
+def test_resize_linear_properties():
+    """cv2.resize stand-in: identity at the same size, constants stay constant, an exact 2 x 2 decimation is the rounded
+    mean, the result stays within the range of the 2 x 2 source neighbourhood, product == oracle bit for bit."""
+    r = np.random.RandomState(3)
+    img = r.randint(0, 256, (41, 57, 3)).astype(np.uint8)
+    assert np.array_equal(O.resize_linear_u8(img, (57, 41)), img)
+    assert np.unique(O.resize_linear_u8(np.full((30, 44, 3), 201, np.uint8), (61, 23))).tolist() == [201]
+    even = img[:40, :56]
+    q = even.astype(np.int64)
+    assert np.array_equal(O.resize_linear_u8(even, (28, 20)), ((q[0::2, 0::2] + q[0::2, 1::2] + q[1::2, 0::2] + q[1::2, 1::2] + 2) >> 2))
+    for ds in ((80, 50), (33, 29), (57, 60), (20, 41), (114, 82)):
+        a, b = O.resize_linear_u8(img, ds), P.resize_linear_u8(img, ds)
+        assert a.shape == (ds[1], ds[0], 3) and np.array_equal(a, b)
+        assert a.min() >= img.min() and a.max() <= img.max()
+        m2 = O.resize_linear_u8(img[..., 0], ds)
+        assert np.array_equal(m2, a[..., 0])                         # channels are independent; 2-D input == one channel
+    ramp = np.tile(np.arange(0, 200, 4, dtype=np.uint8)[None, :, None], (8, 1, 3))   # a linear ramp stays monotone
+    up = O.resize_linear_u8(ramp, (125, 8))[0, :, 0].astype(int)
+    assert (np.diff(up) >= 0).all()
+
+
+def test_poisson_clone_properties():
+    """seamlessClone stand-in: (1) cloning a patch cut from the destination itself changes nothing; (2) the ROI's boundary
+    ring keeps the destination's pixels; (3) a constant offset of the source is invisible (only gradients are cloned);
+    (4) inside the eroded mask the result's Laplacian equals the source's (gradient-domain residual ~ 0, up to the final
+    truncation); (5) an ROI that leaves the image raises, as OpenCV does."""
+    r = np.random.RandomState(5)
+    yy, xx = np.mgrid[0:120, 0:140]
+    dst = np.clip(np.stack([90 + 40 * np.sin(xx / 9.0), 100 + 30 * np.cos(yy / 7.0), 80 + 0.5 * xx], -1) + r.randint(-3, 4, (120, 140, 3)), 0, 255).astype(np.uint8)
+    mask = np.full((40, 60), 255, np.uint8)
+    same = O.seamless_clone(dst[30:70, 40:100].copy(), dst, mask, (40 + 30, 30 + 20))
+    assert np.array_equal(same, dst)                                                                     # (1)
+    src = np.clip(np.stack([120 + 50 * np.sin(yy / 5.0 + xx / 11.0)] * 3, -1), 0, 255).astype(np.uint8)[:40, :60]
+    out = O.seamless_clone(src, dst, mask, (70, 50))
+    y0, x0, h, w = 50 - 38 // 2, 70 - 58 // 2, 38, 58                                                    # roi_d of the cleared-border mask
+    changed = np.argwhere((out != dst).any(-1))
+    assert changed[:, 0].min() >= y0 + 1 and changed[:, 0].max() <= y0 + h - 2                           # (2)
+    assert changed[:, 1].min() >= x0 + 1 and changed[:, 1].max() <= x0 + w - 2
+    assert np.array_equal(out[y0, x0:x0 + w], dst[y0, x0:x0 + w]) and np.array_equal(out[y0:y0 + h, x0], dst[y0:y0 + h, x0])
+    shifted = np.clip(src.astype(int) + 30, 0, 255).astype(np.uint8)
+    assert np.abs(O.seamless_clone(shifted, dst, mask, (70, 50)).astype(int) - out).max() <= 1           # (3)
+    lap = lambda a: (a[1:-1, :-2] + a[1:-1, 2:] + a[:-2, 1:-1] + a[2:, 1:-1] - 4 * a[1:-1, 1:-1])
+    inner = (slice(y0 + 6, y0 + h - 6), slice(x0 + 6, x0 + w - 6))
+    got = lap(out[..., 0].astype(float))[inner[0].start - 1:inner[0].stop - 1, inner[1].start - 1:inner[1].stop - 1]
+    sy, sx = 1 + 6, 1 + 6                                                                                # the same pixels in source coordinates
+    want = lap(src[..., 0].astype(float))[sy - 1:sy - 1 + got.shape[0], sx - 1:sx - 1 + got.shape[1]]
+    assert np.abs(got - want).max() <= 4.0 and np.abs(got - want).mean() < 1.5                           # (4): truncation moves each pixel < 1
+    with pytest.raises(ValueError):
+        O.seamless_clone(src, dst, mask, (5, 5))                                                         # (5)
+    out2 = dst.copy()                                                                                    # the product's host path == the oracle
+    pms = mask.copy(); pms[0] = pms[-1] = 0; pms[:, 0] = pms[:, -1] = 0
+    P.poisson_clone_numpy(out2, src, pms, P.clone_roi(pms, (70, 50), dst.shape[:2]))
+    assert np.array_equal(out2, out)
+
+
+def test_dataset_arguments_follow_the_reference_tables():
+    """anomaly_detection.py:50-65,118-141,254-264: per-class width bounds / logistic parameters / background for MVTec, the
+    VisA set otherwise; both resample the patch and blend with NORMAL_CLONE."""
+    a = P.self_sup_args("mvtec", "screw")
+    assert a["width_bounds_pct"] == ((0.03, 0.12), (0.03, 0.12)) and a["intensity_logistic_params"] == (1, 3) and a["skip_background"] == (200, 60)
+    assert a["resize"] is True and a["mode"] == "normal_clone" and a["num_patches"] == 2 and a["gamma_params"] == (2, 0.05, 0.03)
+    assert P.self_sup_args("mvtec", "carpet")["skip_background"] is None
+    v = P.self_sup_args("visa", "candle")
+    assert v["resize_bounds"] == (.5, 2) and v["width_bounds_pct"] == ((0.03, 0.4), (0.03, 0.4)) and v["intensity_logistic_params"] == (1 / 12, 24)
+
+
+def test_anomaly_detection_dataset_trains_with_the_reference_recipe(tmp_path):
+    """AnomalyDetectionDataset.__getitem__ (anomaly_detection.py:231-362): class name from the path, MVTec tables selected by
+    the annotation file's name, default = resampled patch + Poisson blend; 'swap' is the explicit opt-out."""
+    from PIL import Image
+    from myriad_amd.datasets import AnomalyDetectionDataset
+    import json
+    root = tmp_path
+    rows = []
+    for i in range(3):
+        rel = f"mvtec/hazelnut/train/good/{i:03d}.png"
+        os.makedirs(os.path.dirname(root / rel), exist_ok=True)
+        Image.fromarray(MK.test_image(20 + i, 256)).save(root / rel)
+        rows.append({"img_path": rel, "is_anomaly": "0", "caption": ""})
+    (root / "DC_MVTEC_train_normal.jsonl").write_text("\n".join(json.dumps(r) for r in rows))
+    ds = AnomalyDetectionDataset(str(root), ["DC_MVTEC_train_normal.jsonl"], seed=7)
+    assert ds.get_class_name(0) == ("mvtec", "hazelnut")
+    a = ds[0]
+    assert a["aug_image"].shape == (3, 224, 224) and not torch.equal(a["aug_image"], a["image"])
+    b = AnomalyDetectionDataset(str(root), ["DC_MVTEC_train_normal.jsonl"], seed=7)[0]
+    assert torch.equal(a["aug_image"], b["aug_image"])                              # the dataset's own RandomState drives every draw
+    sw = AnomalyDetectionDataset(str(root), ["DC_MVTEC_train_normal.jsonl"], seed=7, self_sup_mode="swap")[0]
+    assert not torch.equal(sw["aug_image"], a["aug_image"])
+    (root / "visa.jsonl").write_text("\n".join(json.dumps(r) for r in rows))
+    assert AnomalyDetectionDataset(str(root), ["visa.jsonl"], seed=7).get_class_name(1)[0] == "visa"

@@ -8,7 +8,7 @@ from myriad_amd import ops, _lib
 L = _lib.load()
 dev = torch.device("cuda:0")
 ops.ensure_workspace(dev)
-SHAPES = [(648, 768, 768), (648, 768, 2304), (648, 2304, 768), (648, 3072, 768), (648, 768, 3072), (2056, 1536, 1408),
+SHAPES = [(2056, 1408, 1408), (81, 768, 768), (81, 3072, 768), (648, 768, 768), (648, 768, 2304), (648, 2304, 768), (648, 3072, 768), (648, 768, 3072), (2056, 1536, 1408),
           (2056, 1408, 1536), (256, 768, 768), (256, 1408, 640), (648, 4096, 768), (392, 768, 1024)]
 VAR_SHIFT = None
 
@@ -33,7 +33,7 @@ for (M, N, K) in SHAPES:
     outf = torch.empty(M, N, dtype=torch.float32, device=dev)
     k, s = ops.gemm_plan(M, N, K)
     line = f"M={M} N={N} K={K} kt={K//64}: auto(k{k},s{s}) {bench(lambda i: ops.gemm(a, bs[i], out=out), nb):.1f} us"
-    for v in (1, 2, 3, 4, 5, 10):
+    for v in (1, 2, 3, 4, 5, 10, 13, 14):
         line += f" | v{v} {bench(lambda i: ops.gemm(a, bs[i], out=out, variant=v), nb):.1f}"
     print(line, flush=True)
     line = "      split-K (128^2 default kernel + reduce):"

@@ -2,17 +2,19 @@
 """Golden vectors for the NSA / CutPaste self-supervised augmentation: runs the REFERENCE's own
 `patch_ex` (minigpt4/datasets/self_sup_tasks.py:11-292) in this container and commits inputs + outputs.
 
-The reference module imports cv2 and skimage, neither of which is installed here.  What it needs from them on the
-NON-Poisson branches is supplied by import shims built on scipy (an independent implementation, not this repository's code):
+The reference module imports cv2 and skimage, neither of which is installed here.  What it needs from them is supplied by
+import shims:
     cv2.NORMAL_CLONE / MIXED_CLONE     the two integer constants (1, 2)
     cv2.medianBlur(u8, k)              scipy.ndimage.median_filter(size=k, mode='nearest')   [OpenCV: BORDER_REPLICATE]
     skimage.morphology.disk(r)         boolean x^2 + y^2 <= r^2 footprint
     skimage.filters.median(img, fp)    scipy.ndimage.median_filter(footprint=fp, mode='nearest')  [what skimage itself calls]
-    cv2.resize(img, same size)         identity (the skip_background branch resizes the object mask to the unchanged patch size)
-    cv2.resize to another size / cv2.seamlessClone   NOT provided: every case runs with resize=False, mode in {'swap', 'uniform'}.
-Pinned by this fixture: the np.random call sequence of the patch geometry (gamma widths, centres, shifts, the coin flips
-for extra patches, CutPaste area / aspect sampling), the object-mask logic (skip_background), both arithmetic blends and the
-three label modes.  NOT pinned (stated in DESIGN.md): cv2.resize (resize=True) and Poisson blending (cv2.seamlessClone).
+    cv2.resize(u8, (w, h))             oracle/self_sup_ref.resize_linear_u8   -- a restatement of OpenCV's 8-bit INTER_LINEAR
+    cv2.seamlessClone(..NORMAL_CLONE)  oracle/self_sup_ref.seamless_clone     -- a restatement of OpenCV's Poisson cloning
+The first four are independent library implementations: cases that only use them pin the whole function.  The last two are
+this repository's own restatements of published OpenCV algorithms (PARITY UNPINNED, see oracle/self_sup_ref.py): the cases
+with resize=True / mode=cv2.NORMAL_CLONE -- the shipped recipe, datasets/datasets/anomaly_detection.py:118-141,254-264 --
+pin the REFERENCE'S OWN CODE around those two calls (the np.random sequence, the size arithmetic and clipping :213-224, the
+object-mask logic, mask scaling / zeroed border / centre / the 50-pixel rule :271-279, the label), not OpenCV's pixels.
 
 python tools/make_golden_selfsup.py [--ref /root/reference]   ->  tests/golden/self_sup.npz
 """
@@ -39,15 +41,15 @@ def load_reference(ref):
 
     cv2.error = error
 
-    def _no(*a, **k):
-        raise NotImplementedError("cv2.resize / seamlessClone are not available in the build container")
+    from oracle import self_sup_ref as O          # the restated OpenCV algorithms (see the module docstring)
 
-    def _resize(img, dsize):
-        if (img.shape[1], img.shape[0]) == tuple(dsize):
-            return img.copy()                    # a same-size resize is the identity in OpenCV; anything else is not provided
-        _no()
+    def _seamless(src, dst, mask, center, flags):
+        try:
+            return O.seamless_clone(src, dst, mask, center, flags)
+        except ValueError as e:
+            raise error(str(e))
 
-    cv2.resize, cv2.seamlessClone = _resize, _no
+    cv2.resize, cv2.seamlessClone = (lambda img, dsize: O.resize_linear_u8(img, dsize)), _seamless
     sk = types.ModuleType("skimage")
     skm = types.ModuleType("skimage.morphology")
     skf = types.ModuleType("skimage.filters")
@@ -96,6 +98,27 @@ CASES = [
     ("cutpaste", 6, dict(mode="swap", cutpaste_patch_generation=True, label_mode="binary", shift=True)),
     ("uniform_ellipses", 7, dict(mode="uniform", num_patches=2, resize=False, shift=True, label_mode="logistic-intensity", num_ellipses=3,
                                  gamma_params=(2, 0.05, 0.03))),
+    # ---- the shipped recipe: resize=True + Poisson blending, with the per-class argument sets of anomaly_detection.py:50-65,118-141
+    ("swap_resize", 9, dict(mode="swap", num_patches=2, min_object_pct=0, min_overlap_pct=0.25, gamma_params=(2, 0.05, 0.03), resize=True,
+                            shift=True, same=False, label_mode="logistic-intensity", width_bounds_pct=((0.03, 0.4), (0.03, 0.4)))),
+    ("poisson_noresize", 10, dict(mode=1, num_patches=2, min_object_pct=0, min_overlap_pct=0.25, gamma_params=(2, 0.05, 0.03), resize=False,
+                                  shift=True, same=False, label_mode="logistic-intensity", width_bounds_pct=((0.03, 0.4), (0.03, 0.4)),
+                                  intensity_logistic_params=(1 / 3, 7))),
+    ("poisson_mvtec_carpet", 11, dict(mode=1, num_patches=2, min_object_pct=0, min_overlap_pct=0.25, gamma_params=(2, 0.05, 0.03), resize=True,
+                                      shift=True, same=False, label_mode="logistic-intensity", width_bounds_pct=((0.03, 0.4), (0.03, 0.4)),
+                                      intensity_logistic_params=(1 / 3, 7), skip_background=None)),
+    ("poisson_mvtec_hazelnut", 12, dict(mode=1, num_patches=2, min_object_pct=0, min_overlap_pct=0.25, gamma_params=(2, 0.05, 0.03), resize=True,
+                                        shift=True, same=False, label_mode="logistic-intensity", width_bounds_pct=((0.03, 0.35), (0.03, 0.35)),
+                                        intensity_logistic_params=(1 / 12, 24), skip_background=(20, 20))),
+    ("poisson_mvtec_screw", 13, dict(mode=1, num_patches=2, min_object_pct=0, min_overlap_pct=0.25, gamma_params=(2, 0.05, 0.03), resize=True,
+                                     shift=True, same=False, label_mode="logistic-intensity", width_bounds_pct=((0.03, 0.12), (0.03, 0.12)),
+                                     intensity_logistic_params=(1, 3), skip_background=(200, 60))),
+    ("poisson_visa", 14, dict(mode=1, num_patches=2, min_object_pct=0, min_overlap_pct=0.25, gamma_params=(2, 0.05, 0.03), resize=True,
+                              shift=True, same=False, label_mode="logistic-intensity", width_bounds_pct=((0.03, 0.4), (0.03, 0.4)),
+                              intensity_logistic_params=(1 / 12, 24), skip_background=None, resize_bounds=(.5, 2))),
+    ("poisson_visa_b", 15, dict(mode=1, num_patches=2, min_object_pct=0, min_overlap_pct=0.25, gamma_params=(2, 0.05, 0.03), resize=True,
+                                shift=True, same=False, label_mode="logistic-intensity", width_bounds_pct=((0.03, 0.4), (0.03, 0.4)),
+                                intensity_logistic_params=(1 / 12, 24), skip_background=None, resize_bounds=(.5, 2))),
     ("same_source", 8, dict(mode="swap", num_patches=2, resize=False, shift=True, same=True, label_mode="binary", gamma_params=(2, 0.05, 0.03))),
 ]
 

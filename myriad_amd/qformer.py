@@ -65,6 +65,18 @@ class QFormerHIP:
                         L[k + "T"] = L[k].t().contiguous()
             self.layers.append(L)
             i += 1
+        # The key / value projections of every cross-attention layer read the same image tokens (Qformer.py:172-176 with
+        # encoder_hidden_states): one [n_cross * 2D, We] matrix turns 6 GEMMs inside the dependent layer chain into ONE in front
+        # of it (forward) and 6 accumulating dgrad GEMMs into ONE K = n_cross * 2D product behind it (backward); same values
+        # per layer -- each output column is the same dot product.
+        cross = [L for L in self.layers if L["cross"]]
+        self.n_cross = len(cross)
+        if cross:
+            self.cwkv_all = torch.cat([L["cwkv"] for L in cross], 0).contiguous()
+            self.cbkv_all = torch.cat([L["cbkv"] for L in cross], 0).contiguous()
+            self.cwkvT_all = torch.cat([L["cwkvT"] for L in cross], 1).contiguous() if need_backward else None
+            for L in cross:
+                L.pop("cwkv"); L.pop("cbkv"); L.pop("cwkvT", None)
         self._saved = None
 
     def forward(self, query_embeds: torch.Tensor, enc_b: torch.Tensor, save_for_backward: bool = True):
@@ -76,6 +88,8 @@ class QFormerHIP:
         q_in = query_embeds.reshape(M, D).contiguous()
         hb, h = ops.layernorm_fwd(q_in, self.emb_w, self.emb_b, self.eps, want_bf16=True, want_f32=True)
         enc2 = enc_b.reshape(B * Ne, We)
+        ckv_all = ops.gemm(enc2, self.cwkv_all, bias=self.cbkv_all).view(B, Ne, self.n_cross * 2 * D) if self.n_cross else None
+        ci = 0
         saved = []
         for L in self.layers:
             s = {}
@@ -87,7 +101,8 @@ class QFormerHIP:
             s.update(qkv=qkv, ctx=ctx, lse=lse, y_a=y)
             if L["cross"]:
                 cq = ops.gemm(hb, L["cwq"], bias=L["cbq"]).view(B, nq, D)
-                ckv = ops.gemm(enc2, L["cwkv"], bias=L["cbkv"]).view(B, Ne, 2 * D)
+                ckv = ckv_all[:, :, ci * 2 * D:(ci + 1) * 2 * D]
+                ci += 1
                 cctx, clse = ops.attn_fwd(cq, ckv[:, :, :D], ckv[:, :, D:], H, hd, scale)
                 yc = ops.gemm(cctx.view(M, D), L["cwo"], bias=L["cbo"], residual=h, out_dtype=F32)
                 hb, h = ops.layernorm_fwd(yc, L["ln_c_w"], L["ln_c_b"], self.eps, want_bf16=True, want_f32=True)
@@ -111,7 +126,8 @@ class QFormerHIP:
         D, H, hd = self.D, self.H, self.hd
         M = B * nq
         dh = dout.reshape(M, D).contiguous()
-        denc = torch.zeros((B * Ne, We), dtype=F32, device=self.dev)
+        dckv_all = torch.empty((B, Ne, self.n_cross * 2 * D), dtype=BF16, device=self.dev) if self.n_cross else None
+        ci = self.n_cross
         for L, s in zip(reversed(self.layers), reversed(sv["layers"])):
             # FFN:  h_out = LN(y_f),  y_f = act(h W1^T+b1) W2^T + b2 + h
             dy, dyb = ops.layernorm_bwd(dh, s["y_f"], L["ln_f_w"], self.eps, want_bf16=True)
@@ -122,11 +138,11 @@ class QFormerHIP:
                 dy, dyb = ops.layernorm_bwd(dh, s["y_c"], L["ln_c_w"], self.eps, want_bf16=True)
                 dctx = ops.gemm(dyb, L["cwoT"]).view(B, nq, D)
                 ckv = s["ckv"]
-                dckv = torch.empty_like(ckv)
+                ci -= 1
+                dckv = dckv_all[:, :, ci * 2 * D:(ci + 1) * 2 * D]
                 dcq, _, _ = ops.attn_bwd(s["cq"], ckv[:, :, :D], ckv[:, :, D:], s["cctx"], dctx, s["clse"], H, hd, scale,
                                          dk=dckv[:, :, :D], dv=dckv[:, :, D:])
                 dh = ops.gemm(dcq.view(M, D), L["cwqT"], residual=dy, out_dtype=F32)
-                ops.gemm(dckv.view(B * Ne, 2 * D), L["cwkvT"], out=denc, residual=denc)   # accumulate over layers
             dy, dyb = ops.layernorm_bwd(dh, s["y_a"], L["ln_a_w"], self.eps, want_bf16=True)
             dctx = ops.gemm(dyb, L["woT"]).view(B, nq, D)
             qkv = s["qkv"]
@@ -135,5 +151,9 @@ class QFormerHIP:
                          dq=dqkv[:, :, :D], dk=dqkv[:, :, D:2 * D], dv=dqkv[:, :, 2 * D:])
             dh = ops.gemm(dqkv.view(M, 3 * D), L["wqkvT"], residual=dy, out_dtype=F32)
         dq_in, _ = ops.layernorm_bwd(dh, sv["q_in"], self.emb_w, self.eps)
+        if self.n_cross:                                  # d(image tokens) = sum over the cross layers, as one K = n_cross*2D product
+            denc = ops.gemm(dckv_all.view(B * Ne, self.n_cross * 2 * D), self.cwkvT_all, out_dtype=F32)
+        else:
+            denc = torch.zeros((B * Ne, We), dtype=F32, device=self.dev)
         self._saved = None
         return dq_in.view(B, nq, D), denc.view(B, Ne, We)

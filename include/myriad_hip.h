@@ -244,6 +244,21 @@ long mh_gemv_pack_elems(int N, int K);
 int mh_gemv_pack(const void* W, int ldb, int N, int K, void* out, mh_stream_t s);
 int mh_gemv_packed(const void* A, int lda, const void* P, void* C, int ldc, int M, int N, int K, const float* bias,
                    const float* residual, int ldr, int out_f32, float alpha, mh_stream_t s);
+/* The decode step's Linear with the producer of its operand fused in (bit-identical to the two-launch forms): the RMSNorm
+ * in front of q/k/v, gate|up and lm_head (modeling_llama.py:66-74; H [M, K] f32) and the SiLU gate in front of the down
+ * projection (:139-140; gu [M, 2K] bf16, gate / up interleaved in blocks of 128).  Every workgroup rebuilds the <= 16
+ * operand rows in LDS; MH_ERR_UNSUPPORTED when M * K * 2 bytes exceed 64 KiB (use the two-launch form). */
+int mh_gemv_packed_rmsnorm(const float* H, long ldh, const float* norm_w, float eps, const void* P, void* C, int ldc, int M,
+                           int N, int K, const float* bias, const float* residual, int ldr, int out_f32, float alpha,
+                           mh_stream_t s);
+int mh_gemv_packed_silu(const void* gu, long ldgu, const void* P, void* C, int ldc, int M, int N, int K, const float* bias,
+                        const float* residual, int ldr, int out_f32, float alpha, mh_stream_t s);
+/* One decode token of attention (modeling_llama.py:186-222 with the KV cache): rotary on q / k, k | v appended at cache row
+ * pos_dev[0], the one query against kv_len[b] keys -- mh_rope_kv_append + mh_attn_fwd(Sq = 1) in one launch, same bits.
+ * qkv [B, ld_qkv] bf16 = [q | k | v] (q rotated in place), cache [B][T_cap][2 H D] rows [k | v], out [B, H D] bf16. */
+int mh_attn_decode_rope(void* qkv, long ld_qkv, void* cache, long cache_bstride, long ld_cache, const int* pos,
+                        const int* pos_dev, const int* kv_len, const float* cos_tab, const float* sin_tab, void* out, long ldo,
+                        int B, int H, int D, int T_cap, float scale, mh_stream_t s);
 /* K14 patch embedding operand (eva_vit.py:196-204): NCHW f32 image -> [B*np, Kpad] bf16 in (c,iy,ix) order */
 int mh_patchify_nchw(const float* img, void* out, int B, int C, int H, int W, int P, int Kpad, mh_stream_t s);
 int mh_scatter_rows_f32(const float* src, const int* rows, float* dst, long ldd, long n, int D, int accumulate,

@@ -41,6 +41,14 @@ struct AttnParams {
   float scale;
   int causal;
   int q_off;  // key j visible to query i iff j <= i + q_off (causal)
+  // decode token with the rotary + KV append fused in (mh_attn_decode_rope): q / k / v of the new token are columns
+  // [0, W), [W, 2W), [2W, 3W) of qkv rows (W = H*D); the cache row is [k | v]; all NULL / 0 otherwise
+  bf16_t* qkv;
+  long ld_qkv;
+  const float* cs;
+  const float* sn;
+  const int* pos;       // [B] rotary position of the new token
+  const int* pos_dev;   // [1] cache row the new token is appended at
 };
 
 template <int DP>
@@ -436,6 +444,36 @@ __global__ __launch_bounds__(DNW * 64) void attn_decode_kernel(AttnParams p) {
   int len = p.kv_len ? p.kv_len[b] : p.Sk;
   len = len < p.Sk ? len : p.Sk;
   const int D = p.D;
+  if (p.qkv) {
+    // rotary on this head's q (in place) and k, k | v into the cache row -- what rope_kv_append_kernel does for the whole
+    // token (modeling_llama.py:186-195), same arithmetic (fp32 rotate-half, one rounding to bf16), per (b, h) here
+    const int half = D >> 1, items = half >> 2, W = p.H * D;
+    bf16_t* src = p.qkv + (size_t)b * p.ld_qkv;
+    bf16_t* crow = const_cast<bf16_t*>(p.k) + (size_t)b * p.k_bs + (size_t)p.pos_dev[0] * p.ldk;
+    if (tid < 2 * items) {
+      const int which = tid / items, i = (tid % items) * 4;
+      bf16_t* e = src + which * W + h * D + i;
+      const int ps = p.pos[b];
+      const float4_t c4 = *reinterpret_cast<const float4_t*>(p.cs + (size_t)ps * half + i);
+      const float4_t s4 = *reinterpret_cast<const float4_t*>(p.sn + (size_t)ps * half + i);
+      const short4_t a = *reinterpret_cast<const short4_t*>(e);
+      const short4_t bb = *reinterpret_cast<const short4_t*>(e + half);
+      short4_t oa, ob;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float x1 = bf2f((bf16_t)a[t]), x2 = bf2f((bf16_t)bb[t]);
+        oa[t] = (short)f2bf(x1 * c4[t] - x2 * s4[t]);
+        ob[t] = (short)f2bf(x2 * c4[t] + x1 * s4[t]);
+      }
+      bf16_t* dst = which == 0 ? e : crow + h * D + i;
+      *reinterpret_cast<short4_t*>(dst) = oa;
+      *reinterpret_cast<short4_t*>(dst + half) = ob;
+    } else if (tid < 2 * items + (D >> 3)) {
+      const int c = (tid - 2 * items) * 8;
+      *reinterpret_cast<short8_t*>(crow + W + h * D + c) = *reinterpret_cast<const short8_t*>(src + 2 * W + h * D + c);
+    }
+    __syncthreads();                               // the row is read back below by other waves of this workgroup
+  }
   const bf16_t* qp = p.q + (size_t)b * p.q_bs + h * D;
   const bf16_t* kp = p.k + (size_t)b * p.k_bs + h * D;
   const bf16_t* vp = p.v + (size_t)b * p.v_bs + h * D;
@@ -591,6 +629,30 @@ extern "C" int mh_attn_fwd(const void* q, const void* k, const void* v, void* o,
   if (D <= 64) return launch_fwd<64>(p, stream);
   if (D <= 96) return launch_fwd<96>(p, stream);
   return launch_fwd<128>(p, stream);
+}
+
+// One decode token: rotary on q / k, k | v appended to the cache at row pos_dev[0], attention of the one query over
+// kv_len[b] keys -- mh_rope_kv_append + mh_attn_fwd(Sq = 1) in one launch, bit-identical to the pair.
+// qkv [B, ld_qkv] bf16 = [q | k | v] (q is rotated in place); cache [B][T_cap][2W] bf16 rows [k | v]; out [B, W] bf16.
+extern "C" int mh_attn_decode_rope(void* qkv, long ld_qkv, void* cache, long cache_bstride, long ld_cache, const int* pos,
+                                   const int* pos_dev, const int* kv_len, const float* cos_tab, const float* sin_tab, void* out,
+                                   long ldo, int B, int H, int D, int T_cap, float scale, hipStream_t stream) {
+  if (B <= 0) return MH_OK;
+  if (!qkv || !cache || !pos || !pos_dev || !kv_len || !cos_tab || !sin_tab || !out) return MH_ERR_ARG;
+  if (D % 8 || D > 128 || (D >> 1) % 4 || ld_qkv % 8 || ld_cache % 8 || cache_bstride % 8 || ldo % 4 || T_cap <= 0 || T_cap > 8192)
+    return MH_ERR_ARG;
+  const int W = H * D;
+  AttnParams p = {};
+  p.q = (const bf16_t*)qkv; p.k = (const bf16_t*)cache; p.v = (const bf16_t*)cache + W; p.o = (bf16_t*)out;
+  p.kv_len = kv_len; p.B = B; p.H = H; p.Sq = 1; p.Sk = T_cap; p.D = D;
+  p.q_bs = ld_qkv; p.k_bs = cache_bstride; p.v_bs = cache_bstride; p.o_bs = ldo;
+  p.ldq = (int)ld_qkv; p.ldk = (int)ld_cache; p.ldv = (int)ld_cache; p.ldo = (int)ldo;
+  p.scale = scale; p.causal = 0; p.q_off = T_cap - 1;
+  p.qkv = (bf16_t*)qkv; p.ld_qkv = ld_qkv; p.cs = cos_tab; p.sn = sin_tab; p.pos = pos; p.pos_dev = pos_dev;
+  const size_t sh = (((size_t)T_cap + 63) & ~(size_t)63) * 4 + DNW * 128 * 4;
+  hipLaunchKernelGGL(attn_decode_kernel, dim3(B * H), dim3(DNW * 64), sh, stream, p);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
 }
 
 extern "C" int mh_attn_bwd(const void* q, const void* k, const void* v, const void* o, const void* dout,

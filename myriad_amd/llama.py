@@ -89,6 +89,7 @@ class LlamaHIP:
         # the LoRA weight gradients feed only the optimiser: queued during the dgrad chain, launched on a side stream after it
         # (55.7 -> 55.1 ms per step: they run beside the Q-Former backward); MYRIAD_LORA_DEFER=0 computes them in place
         self.defer_lora_wgrad = os.environ.get("MYRIAD_LORA_DEFER", "1") != "0"
+        self.decode_fused = os.environ.get("MYRIAD_DECODE_FUSED", "1") != "0"
         self._packed = None
         self._decode_ws = {}
 
@@ -258,7 +259,25 @@ class LlamaHIP:
                 return ops.gemv_packed(x, packed[li]["wqkv" if name.startswith("wqkv") else name], **kw)
             return ops.gemm(x, self.layers[li][name], **kw)
 
+        # Single-token step on the packed copies without LoRA: four launches per layer instead of nine -- the two RMSNorms
+        # and the SiLU gate are rebuilt by every workgroup of the product that consumes them (mh_gemv_packed_rmsnorm /
+        # _silu), rotary + KV append ride the attention launch (mh_attn_decode_rope); each fused form is bit-identical
+        # to the launches it replaces (tests/test_kernels_gpu.py), MYRIAD_DECODE_FUSED=0 keeps the separate launches.
+        fused = packed is not None and self.lora is None and self.decode_fused
         for li, (L, cache) in enumerate(zip(self.layers, caches)):
+            if fused:
+                P = packed[li]
+                qkv = ops.gemv_packed_rmsnorm(h, L["ln1"], self.eps, P["wqkv"])
+                if qkv is None:
+                    qkv = ops.gemv_packed(ops.rmsnorm_fwd(h, L["ln1"], self.eps), P["wqkv"])
+                o = ops.attn_decode_rope(qkv, cache, pos, pos_dev, kvlen_dev, self.cos, self.sin, H, hd, scale)
+                h2 = ops.gemv_packed(o, P["wo"], residual=h, out_dtype=F32)
+                gu = ops.gemv_packed_rmsnorm(h2, L["ln2"], self.eps, P["wgu"])
+                if gu is None:
+                    gu = ops.gemv_packed(ops.rmsnorm_fwd(h2, L["ln2"], self.eps), P["wgu"])
+                hn = ops.gemv_packed_silu(gu, P["wd"], residual=h2, out_dtype=F32)
+                h = hn if hn is not None else ops.gemv_packed(ops.silu_mul_fwd_blk(gu), P["wd"], residual=h2, out_dtype=F32)
+                continue
             if self.lora is None:
                 xn = ops.rmsnorm_fwd(h, L["ln1"], self.eps)
                 qkv = lin(li, "wqkv", xn)
@@ -288,7 +307,7 @@ class LlamaHIP:
         counters, id / logit / result buffers and per-step histories.  Kept across generate() calls -- an evaluation run
         calls generate() once per batch, and re-capturing ~290 launches each time cost ~9 ms per call."""
         T_cap = ops.round_up(T_need + 2, 64)
-        key = (B, T_cap, float(inv_temp), id(self._packed), None if self._packed is None else self._packed.get("qkv_key"),
+        key = (B, T_cap, float(inv_temp), id(self._packed), None if self._packed is None else self._packed.get("qkv_key"), self.decode_fused,
                self.lora is not None)
         ws = self._decode_ws.get(key)
         if ws is None:
@@ -397,11 +416,15 @@ class LlamaHIP:
         def token_step(ban):
             ops.embed_gather(self.embed, ws["ids"], ws["x_in"])
             hh = self._decode_block(ws["x_in"], B, 1, caches, scale, ws["pos"], pos_dev=ws["pos"], kvlen_dev=ws["kvlen"])
-            hn = ops.rmsnorm_fwd(hh, self.norm, self.eps)
-            if self._packed is not None and B <= 16:
-                ops.gemv_packed(hn, self._packed["lm_head"], out=ws["logits"], out_dtype=F32)
-            else:
-                ops.gemm(hn, self.lm_head, out=ws["logits"])
+            done_lm = None
+            if self._packed is not None and B <= 16 and self.decode_fused:
+                done_lm = ops.gemv_packed_rmsnorm(hh, self.norm, self.eps, self._packed["lm_head"], out=ws["logits"], out_dtype=F32)
+            if done_lm is None:
+                hn = ops.rmsnorm_fwd(hh, self.norm, self.eps)
+                if self._packed is not None and B <= 16:
+                    ops.gemv_packed(hn, self._packed["lm_head"], out=ws["logits"], out_dtype=F32)
+                else:
+                    ops.gemm(hn, self.lm_head, out=ws["logits"])
             ops.argmax_pmax_rows(ws["logits"], ws["nxt"], ws["mar"], ws["pmx"], ban_id=ban, inv_temp=inv_temp)
             ops.decode_record(ws["nxt"], ws["mar"], ws["pmx"], ws["rec"], ws["ids"], ws["step"])
             ops.add_i32_(ws["pos"], 1)

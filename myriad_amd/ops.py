@@ -210,6 +210,58 @@ def gemv_packed(a: torch.Tensor, pw: PackedWeight, out: Optional[torch.Tensor] =
     return out
 
 
+def _gemv_pro(fn, name, a, lda, pw, out, residual, out_dtype, alpha, M, *pre):
+    if out is None:
+        out = torch.empty((M, pw.N), dtype=out_dtype, device=a.device)
+    ldr = 0
+    if residual is not None:
+        _chk2d(residual, F32, name + ".residual")
+        ldr = residual.stride(0)
+    rc = fn(_p(a), lda, *pre, _p(pw.data), _p(out), out.stride(0), M, pw.N, pw.K, None, _p(residual), ldr,
+            1 if out.dtype == F32 else 0, float(alpha), _s())
+    if rc == -3:                                   # MH_ERR_UNSUPPORTED: the operand rows do not fit the kernel's LDS budget
+        return None
+    _lib.check(rc, f"{name} M={M} N={pw.N} K={pw.K}")
+    return out
+
+
+def gemv_packed_rmsnorm(h: torch.Tensor, norm_w: torch.Tensor, eps: float, pw: PackedWeight, out=None, residual=None,
+                        out_dtype=BF16, alpha: float = 1.0):
+    """out[M<=16, N] = alpha * rmsnorm(h; norm_w, eps) @ W^T (+residual): mh_rmsnorm_fwd + mh_gemv_packed in one launch, same bits.
+    Returns None when the operand rows exceed the fused kernel's LDS budget (run the two launches instead)."""
+    _chk2d(h, F32, "gemv_packed_rmsnorm.h")
+    M, K = h.shape
+    if K != pw.K or M > 16:
+        raise _lib.MyriadHipError(f"gemv_packed_rmsnorm: h is {tuple(h.shape)}, weight was packed as [{pw.N}, {pw.K}]")
+    return _gemv_pro(_L().mh_gemv_packed_rmsnorm, "mh_gemv_packed_rmsnorm", h, h.stride(0), pw, out, residual, out_dtype, alpha, M,
+                     _p(norm_w), float(eps))
+
+
+def gemv_packed_silu(gu: torch.Tensor, pw: PackedWeight, out=None, residual=None, out_dtype=BF16, alpha: float = 1.0):
+    """out[M<=16, N] = alpha * (silu(g) * u) @ W^T (+residual) for gu [M, 2K] bf16 in the 128-blocked gate|up layout:
+    mh_silu_mul_fwd_blk + mh_gemv_packed in one launch, same bits.  None when the rows exceed the LDS budget."""
+    _chk2d(gu, BF16, "gemv_packed_silu.gu")
+    M = gu.shape[0]
+    if gu.shape[1] != 2 * pw.K or M > 16:
+        raise _lib.MyriadHipError(f"gemv_packed_silu: gu is {tuple(gu.shape)}, weight was packed as [{pw.N}, {pw.K}]")
+    return _gemv_pro(_L().mh_gemv_packed_silu, "mh_gemv_packed_silu", gu, gu.stride(0), pw, out, residual, out_dtype, alpha, M)
+
+
+def attn_decode_rope(qkv2d: torch.Tensor, cache: torch.Tensor, pos: torch.Tensor, pos_dev: torch.Tensor, kv_len: torch.Tensor,
+                     cos_tab: torch.Tensor, sin_tab: torch.Tensor, n_heads: int, head_dim: int, scale: float):
+    """One decode token: rope_kv_append + attn_fwd(Sq = 1) as one launch (same bits).  qkv2d [B, >=3W] bf16 (q rotated in place),
+    cache [B, T, 2W]; returns o [B, W] bf16."""
+    _chk2d(qkv2d, BF16, "attn_decode_rope.qkv")
+    B, W = qkv2d.shape[0], n_heads * head_dim
+    if qkv2d.shape[1] < 3 * W or cache.shape[2] != 2 * W:
+        raise _lib.MyriadHipError("attn_decode_rope: qkv must be [B, >=3W] and cache [B, T, 2W]")
+    out = torch.empty((B, W), dtype=BF16, device=qkv2d.device)
+    _lib.check(_L().mh_attn_decode_rope(_p(qkv2d), qkv2d.stride(0), _p(cache), cache.stride(0), cache.stride(1), _p(pos), _p(pos_dev),
+                                        _p(kv_len), _p(cos_tab), _p(sin_tab), _p(out), out.stride(0), B, n_heads, head_dim,
+                                        cache.shape[1], float(scale), _s()), "mh_attn_decode_rope")
+    return out
+
+
 def gemm_auto_f32(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     """f32 out = a @ b^T, choosing split-K when the output is small and the reduction long (wgrad shapes)."""
     M, K = a.shape

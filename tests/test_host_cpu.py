@@ -244,8 +244,8 @@ def test_gemm_policy_for_the_steps_shapes():
         assert plan(1184, 4096, 22016) == (2, 3)                                         # dgrad: 80 tiles -> 240 workgroups
         assert plan(1184, 4096, 4096) == (2, 3)
         assert plan(2056, 6144, 1408) == (2, 1)                                          # ViT fc1
-        k, s = plan(2056, 1408, 1408)                                                    # 54 tiles of 256^2: stays on 128^2
-        assert k == 1 and s >= 1
+        assert plan(2056, 1408, 1408) == (3, 1)                                          # ViT proj: 187 tiles of 128^2 < 256 CUs -> 128x64 tiles
+        assert plan(4096, 25600, 128)[0] == 1                                            # K = 128 (VETokenizer head wgrad): 128x128 kernel
         assert plan(256, 768, 768)[0] == 3 and plan(648, 768, 2304)[0] == 3              # Q-Former sizes: 128x64 tiles fill more CUs
         assert plan(72, 4096, 25664)[0] == 1                                             # conv-stem head: 16 K splits fill the chip
         lib.mh_set_workspace(None, 0)

@@ -165,6 +165,73 @@ def test_decode_kernel_on_the_packed_weight_copy_is_bit_identical(M, N, K):
         ops.gemv_packed(bf(rnd(17, K)).to(DEV), pw)
 
 
+@pytest.mark.parametrize("M,N,K", [(1, 12288, 4096), (2, 4096, 4096), (2, 22016, 4096), (1, 32000, 4096), (1, 1000, 8192)])
+def test_decode_gemv_with_the_rmsnorm_fused_in_is_bit_identical(M, N, K):
+    """mh_gemv_packed_rmsnorm: every workgroup rebuilds the normalised rows (rmsnorm_fwd_kernel's summation order and
+    expression) in LDS, then streams the packed weight -- the SAME bits as mh_rmsnorm_fwd + mh_gemv_packed, with / without the
+    fp32 residual, bf16 and f32 outputs, both wave counts (N / 16 below and above 512 workgroups)."""
+    h = (rnd(M, K, seed=71) * 1.7).to(DEV)
+    w = (1 + 0.1 * rnd(K, seed=72)).to(DEV)
+    b = bf(rnd(N, K, seed=73) * 0.05).to(DEV)
+    res = rnd(M, N, seed=74).to(DEV)
+    pw = ops.gemv_pack(b)
+    xn = ops.rmsnorm_fwd(h, w, 1e-6)
+    assert torch.equal(ops.gemv_packed_rmsnorm(h, w, 1e-6, pw), ops.gemv_packed(xn, pw))
+    got = ops.gemv_packed_rmsnorm(h, w, 1e-6, pw, residual=res, out_dtype=torch.float32)
+    assert torch.equal(got, ops.gemv_packed(xn, pw, residual=res, out_dtype=torch.float32))
+    ref = (h.double() * torch.rsqrt(h.double().pow(2).mean(-1, keepdim=True) + 1e-6) * w.double()) @ b.double().T + res.double()
+    assert relerr(got, ref) < 2e-2
+
+
+def test_decode_gemv_fused_forms_refuse_more_than_two_rows():
+    """Every workgroup rebuilds all M operand rows, which only pays for one or two (measured: batch-8 decode 6.5 vs 4.1 ms per
+    token): beyond that the entry points return MH_ERR_UNSUPPORTED (None here) and the caller runs the two launches."""
+    K, N = 4096, 4096
+    pw = ops.gemv_pack(bf(rnd(N, K, seed=75) * 0.05).to(DEV))
+    w = torch.ones(K, device=DEV)
+    assert ops.gemv_packed_rmsnorm(rnd(16, K, seed=76).to(DEV), w, 1e-6, pw) is None
+    assert ops.gemv_packed_rmsnorm(rnd(3, K, seed=77).to(DEV), w, 1e-6, pw) is None
+
+
+@pytest.mark.parametrize("M", [1, 2])
+def test_decode_gemv_with_the_silu_gate_fused_in_is_bit_identical(M):
+    """mh_gemv_packed_silu on the 128-blocked gate|up layout == mh_silu_mul_fwd_blk + mh_gemv_packed (LLaMA-7B's down
+    projection: K = 11008, N = 4096), fp32 residual."""
+    I, N = 11008, 4096
+    gu = bf(rnd(M, 2 * I, seed=81) * 2.0).to(DEV)
+    b = bf(rnd(N, I, seed=82) * 0.05).to(DEV)
+    res = rnd(M, N, seed=83).to(DEV)
+    pw = ops.gemv_pack(b)
+    act = ops.silu_mul_fwd_blk(gu)
+    got = ops.gemv_packed_silu(gu, pw, residual=res, out_dtype=torch.float32)
+    assert torch.equal(got, ops.gemv_packed(act, pw, residual=res, out_dtype=torch.float32))
+    assert torch.equal(ops.gemv_packed_silu(gu, pw), ops.gemv_packed(act, pw))
+    assert ops.gemv_packed_silu(bf(rnd(4, 2 * I, seed=84)).to(DEV), pw) is None           # 4 x 22 KiB: does not fit
+
+
+@pytest.mark.parametrize("B", [1, 3])
+def test_decode_attention_with_rotary_and_append_fused_in_is_bit_identical(B):
+    """mh_attn_decode_rope == mh_rope_kv_append + mh_attn_fwd(Sq = 1): same rotated q (in place), same cache row, same output."""
+    H, hd, T, pos = 32, 128, 192, 41
+    W = H * hd
+    qkv0 = bf(rnd(B, 3 * W, seed=91)).to(DEV)
+    cache0 = bf(rnd(B, T, 2 * W, seed=92)).to(DEV)
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    ang = torch.arange(T).float()[:, None] * inv[None]
+    cos, sin = ang.cos().contiguous().to(DEV), ang.sin().contiguous().to(DEV)
+    pos_t = torch.full((B,), pos, dtype=torch.int32, device=DEV)
+    kvlen = torch.full((B,), pos + 1, dtype=torch.int32, device=DEV)
+    scale = 1.0 / hd ** 0.5
+    qa, ca = qkv0.clone(), cache0.clone()
+    ops.rope_kv_append(qa, H, hd, pos_t, cos, sin, ca, pos_t)
+    oa, _ = ops.attn_fwd(qa.view(B, 1, 3 * W)[:, :, :W], ca[:, :, :W], ca[:, :, W:], H, hd, scale, causal=False, kv_len=kvlen, need_lse=False)
+    qb, cb = qkv0.clone(), cache0.clone()
+    ob = ops.attn_decode_rope(qb, cb, pos_t, pos_t, kvlen, cos, sin, H, hd, scale)
+    assert torch.equal(qa[:, :W], qb[:, :W]) and torch.equal(ca, cb)
+    assert torch.equal(oa.view(B, W), ob)
+    assert not torch.equal(cb[:, pos], cache0[:, pos])                                      # the row was really written
+
+
 @pytest.mark.parametrize("M,N,K", [(1184, 4096, 4096), (1184, 4096, 11008), (300, 512, 256), (2056, 1408, 6144), (148, 4096, 11008)])
 def test_gemm_residual_rmsnorm_is_bit_identical_to_two_launches(M, N, K):
     """Split-K reduce + residual add + RMSNorm in one kernel (split shapes) or GEMM then norm (the rest): same bits."""

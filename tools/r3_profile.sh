@@ -1,15 +1,31 @@
 #!/bin/bash
-# Round-3 measured artifacts on a GPU box (through gpurun): bench line + per-shape launch profile, rocprofv3 kernel trace of
-# the same command -> step breakdown (profiled region between the marker kernels first), main-stream gap analysis.
+# Round-3 measured artifacts on a GPU box (through gpurun; outputs in gpurun_out/<tag>/, copy the summaries to profiles/):
+#   bench line + per-shape launch profile; rocprofv3 kernel trace of the same command -> step breakdown (the profiled step
+#   between the two marker kernels first) + main-stream gaps; three PMC passes (MFMA busy, FETCH_SIZE, WRITE_SIZE; each with
+#   --kernel-trace only) -> per-kernel table + per-launch-grid traffic of the dominant kernel; decode bench + trace.
 R=$(pwd); O=$R/gpurun_out/${1:-r3p}; mkdir -p $O
 BENCH_SHAPES=$O/step_gemm_shapes.csv python bench.py > $O/bench.log 2>&1; tail -1 $O/bench.log > $O/bench_n1.json
 cd /tmp && export TMPDIR=/tmp
 BENCH_SHAPES=$O/step_gemm_shapes_profiled.csv timeout 900 rocprofv3 --kernel-trace -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline > $O/kt.log 2>&1
+timeout 600 rocprofv3 --kernel-trace -d $O/ktdec -o dec -- python $R/tools/decode_bench.py --new 96 > $O/ktdec.log 2>&1
+mkdir -p $O/pmc
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc/m1 -o m1 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-probe > $O/pmc/m1.log 2>&1
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc/$C -o $C -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-probe > $O/pmc/$C.log 2>&1
+done
 cd $R
 DB=$(find $O/kt -name "*.db" | head -1)
 tail -1 $O/kt.log > $O/bench_under_rocprof.json
 python tools/rocpd_stats.py $DB 8 > $O/kernel_trace.md 2>&1
 python tools/rocpd_step.py $DB > $O/step_breakdown.md 2>&1
 python tools/rocpd_gaps.py $DB > $O/step_gaps.md 2>&1
-rm -rf $O/kt
-head -c 1500 $O/bench_n1.json; echo; head -30 $O/step_gaps.md
+python tools/rocpd_stats.py $(find $O/ktdec -name "*.db" | head -1) > $O/decode_trace.md 2>&1
+python tools/pmc_traffic.py $O/pmc --json $O/gemm256_traffic.json > $O/step_traffic.md 2>&1
+mkdir -p $O/pmc/flat; for t in m1 FETCH_SIZE WRITE_SIZE; do for f in $(find $O/pmc/$t -name "*counter_collection.csv" -o -name "*kernel_trace.csv"); do cp $f $O/pmc/flat/; done; done
+ls $O/pmc/flat > $O/pmc_files.txt
+python tools/decode_bench.py --new 96 2>&1 | tail -1 > $O/decode.log
+python tools/decode_bench.py --new 96 --batch 8 2>&1 | tail -1 >> $O/decode.log
+MYRIAD_DECODE_FUSED=0 python tools/decode_bench.py --new 96 2>&1 | tail -1 >> $O/decode.log
+nproc > $O/host.txt; rocm-smi --showclocks --showpower 2>/dev/null | head -30 >> $O/host.txt
+rm -rf $O/kt $O/ktdec
+head -c 1200 $O/bench_n1.json; echo; cat $O/decode.log; head -12 $O/step_traffic.md

@@ -22,7 +22,8 @@ python tools/rocpd_gaps.py $DB > $O/step_gaps.md 2>&1
 python tools/rocpd_stats.py $(find $O/ktdec -name "*.db" | head -1) > $O/decode_trace.md 2>&1
 python tools/pmc_traffic.py $O/pmc --json $O/gemm256_traffic.json > $O/step_traffic.md 2>&1
 mkdir -p $O/pmc/flat; for t in m1 FETCH_SIZE WRITE_SIZE; do for f in $(find $O/pmc/$t -name "*counter_collection.csv" -o -name "*kernel_trace.csv"); do cp $f $O/pmc/flat/; done; done
-ls $O/pmc/flat > $O/pmc_files.txt
+python tools/pmc_summary.py $O/pmc/flat m1 FETCH_SIZE WRITE_SIZE > $O/step_pmc.md 2>&1
+rm -rf $O/pmc                     # raw per-dispatch csv files are large; the summaries are what gets committed
 python tools/decode_bench.py --new 96 2>&1 | tail -1 > $O/decode.log
 python tools/decode_bench.py --new 96 --batch 8 2>&1 | tail -1 >> $O/decode.log
 MYRIAD_DECODE_FUSED=0 python tools/decode_bench.py --new 96 2>&1 | tail -1 >> $O/decode.log

@@ -91,7 +91,10 @@ class LaunchProfile:
                                   torch.cuda.current_stream().cuda_stream)
         if n < 0:
             raise RuntimeError(f"mh_prof_stop failed: {n}")
-        self.records = [(tuple(meta[6 * i:6 * i + 6]), float(ms[i])) for i in range(n)]
+        # an event pair around NOTHING still reads the queue's marker-to-marker time (calibrated by mh_prof_start: median of 33
+        # empty pairs); every bracketed launch carries it on top of the kernel's own duration, so it is taken off each record
+        self.overhead_ms = float(self.lib.mh_prof_overhead_ms())
+        self.records = [(tuple(meta[6 * i:6 * i + 6]), max(float(ms[i]) - self.overhead_ms, 1e-4)) for i in range(n)]
 
     def summary(self):
         """per kernel and per (kernel, M, N, K, splits): launches, total ms, TFLOP/s, algorithmic bytes per launch
@@ -399,8 +402,10 @@ def main():
                 roof = dict(bound="mfma", kernel=dname, achieved=dk["tflops"], peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
                             frac=round(dk["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=traffic,
                             population="every launch of the kernel in one step (LLaMA fwd + dgrad, ViT fwd; split-K launches "
-                                       "included, each timed alone by a HIP-event pair on its stream)",
+                                       "included, each timed alone by a HIP-event pair on its stream, minus the calibrated "
+                                       "duration of an empty pair)",
                             launches_per_step=dk["launches"], avg_launch_us=dk["avg_us"], kernel_ms_per_step=dk["total_ms"],
+                            event_pair_overhead_us=round(1e3 * lp.overhead_ms, 2),
                             unsplit_launches=lp.subset(did, lambda sp: sp == 1), split_launches=lp.subset(did, lambda sp: sp > 1),
                             per_kernel=per,
                             by_shape=[dict(kernel=KERNEL_NAMES.get(kid, kid), M=m, N=n, K=k, splits=sp, launches=cnt,

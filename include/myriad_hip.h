@@ -52,6 +52,7 @@ int mh_gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits);
  * (2 per record) are created once and reused.  One host thread.  Both calls launch a one-wave no-op kernel
  * (mh_prof_marker_kernel) on `s`, so that a rocprofv3 kernel trace of the same run shows where the profiled region lies. */
 int mh_prof_start(int capacity, mh_stream_t s);
+double mh_prof_overhead_ms(void); /* median of 33 EMPTY event pairs timed by the last mh_prof_start: what a pair adds to a launch */
 int mh_prof_stop(int* meta, float* ms, int cap, mh_stream_t s);
 
 /* Linear + residual add + the RMSNorm that consumes the sum (modeling_llama.py:281-293 then :66-74 of the next block):

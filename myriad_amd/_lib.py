@@ -24,9 +24,9 @@ def parse_header(path: str = HEADER_PATH) -> Dict[str, Tuple[object, List[object
     txt = open(path).read()
     txt = re.sub(r"/\*.*?\*/", " ", txt, flags=re.S)
     out = {}
-    for m in re.finditer(r"\b(int|long|const char\*)\s+(mh_\w+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
+    for m in re.finditer(r"\b(int|long|double|const char\*)\s+(mh_\w+)\s*\(([^;{]*?)\)\s*;", txt, flags=re.S):
         ret, name, args = m.group(1), m.group(2), " ".join(m.group(3).split())
-        restype = {"int": ctypes.c_int, "long": ctypes.c_long, "const char*": ctypes.c_char_p}[ret]
+        restype = {"int": ctypes.c_int, "long": ctypes.c_long, "double": ctypes.c_double, "const char*": ctypes.c_char_p}[ret]
         argtypes = []
         if args and args != "void":
             for a in args.split(","):

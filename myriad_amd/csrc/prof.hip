@@ -10,6 +10,8 @@ struct MhProfRec { hipEvent_t e0, e1; int meta[6]; };   // kernel id (mh_gemm_pl
 static MhProfRec* g_rec = nullptr;
 static int g_cap = 0, g_n = 0, g_open = -1;
 bool g_mh_prof_on = false;
+static float g_overhead_ms = 0.f;
+extern "C" double mh_prof_overhead_ms(void) { return (double)g_overhead_ms; }
 
 // A named no-op: the two ends of the profiled region in a rocprofv3 kernel trace of the same run (tools/rocpd_step.py)
 __global__ void mh_prof_marker_kernel(int which) { (void)which; }
@@ -27,6 +29,22 @@ extern "C" int mh_prof_start(int capacity, hipStream_t stream) {
   }
   g_n = 0;
   g_open = -1;
+  // calibration: an event pair with NOTHING between its two records still measures the queue's marker-to-marker time; the
+  // median of 33 such pairs is what every bracketed launch carries on top of the kernel's own duration (mh_prof_overhead_ms)
+  {
+    hipEvent_t c0[33], c1[33];
+    float t[33];
+    bool ok = true;
+    for (int i = 0; i < 33 && ok; ++i) ok = hipEventCreate(&c0[i]) == hipSuccess && hipEventCreate(&c1[i]) == hipSuccess;
+    for (int i = 0; i < 33 && ok; ++i) ok = hipEventRecord(c0[i], stream) == hipSuccess && hipEventRecord(c1[i], stream) == hipSuccess;
+    if (ok) ok = hipStreamSynchronize(stream) == hipSuccess;
+    for (int i = 0; i < 33 && ok; ++i) ok = hipEventElapsedTime(&t[i], c0[i], c1[i]) == hipSuccess;
+    if (ok) {
+      for (int i = 1; i < 33; ++i) { float v = t[i]; int j = i - 1; while (j >= 0 && t[j] > v) { t[j + 1] = t[j]; --j; } t[j + 1] = v; }
+      g_overhead_ms = t[16];
+    }
+    for (int i = 0; i < 33; ++i) { (void)hipEventDestroy(c0[i]); (void)hipEventDestroy(c1[i]); }
+  }
   hipLaunchKernelGGL(mh_prof_marker_kernel, dim3(1), dim3(64), 0, stream, 0);
   MH_CHECK_LAUNCH();
   g_mh_prof_on = true;

@@ -15,7 +15,7 @@ for C in FETCH_SIZE WRITE_SIZE; do
 done
 cd $R
 DB=$(find $O/kt -name "*.db" | head -1)
-tail -1 $O/kt.log > $O/bench_under_rocprof.json
+grep '^{' $O/kt.log | tail -1 > $O/bench_under_rocprof.json
 python tools/rocpd_stats.py $DB 8 > $O/kernel_trace.md 2>&1
 python tools/rocpd_step.py $DB > $O/step_breakdown.md 2>&1
 python tools/rocpd_gaps.py $DB > $O/step_gaps.md 2>&1

@@ -252,6 +252,28 @@ __global__ __launch_bounds__(GV_NW * 64) void gemv_pro_kernel(const void* __rest
   const int nsteps = K / 64;
   const int per = (nsteps + GV_NW - 1) / GV_NW;
   const bf16_t* wp = B + ((size_t)blockIdx.x * GV_NW + wave) * per * 1024 + lane * 8;
+  // The weight stream does not depend on the operand: the first UNROLL steps of it are put in flight BEFORE the rows are
+  // built (every workgroup of a launch starts at the same time; without this the HBM pipe idles for the ~3 us the prologue
+  // takes).  Vector loads retire in order, so what the prologue needs first -- the fp32 row and the norm weights -- is
+  // requested ahead of the weights.
+  int s = wave * per;
+  const int s0 = s;
+  const int s_end = (s + per) < nsteps ? (s + per) : nsteps;
+  bool have = s + UNROLL <= s_end;
+  short8_t w0[UNROLL], w1[UNROLL];
+  float4_t hv[4];                                               // PRO 2: K <= 4096 (checked by the launcher)
+  if (PRO == 2 && tid < 256) {
+    const float* xr = reinterpret_cast<const float*>(Ain);
+    int c = 0;
+    for (int i = tid * 4; i < K; i += 1024, ++c) hv[c] = *reinterpret_cast<const float4_t*>(xr + i);
+  }
+  if (have) {
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u) {
+      w0[u] = __builtin_nontemporal_load(reinterpret_cast<const short8_t*>(wp + (size_t)u * 1024));
+      w1[u] = __builtin_nontemporal_load(reinterpret_cast<const short8_t*>(wp + (size_t)u * 1024 + 512));
+    }
+  }
   if (PRO == 1) {
     const bf16_t* gu = reinterpret_cast<const bf16_t*>(Ain);
     const int per_row = K >> 3;
@@ -272,12 +294,11 @@ __global__ __launch_bounds__(GV_NW * 64) void gemv_pro_kernel(const void* __rest
     const float* h = reinterpret_cast<const float*>(Ain);
     for (int m = 0; m < M; ++m) {
       const float* xr = h + (size_t)m * lda;
-      float4_t hv[8];                                         // K <= 8192
       float ss = 0.f;
       int c = 0;
       if (tid < 256)
         for (int i = tid * 4; i < K; i += 1024, ++c) {
-          hv[c] = *reinterpret_cast<const float4_t*>(xr + i);
+          if (m > 0) hv[c] = *reinterpret_cast<const float4_t*>(xr + i);
           ss += hv[c][0] * hv[c][0] + hv[c][1] * hv[c][1] + hv[c][2] * hv[c][2] + hv[c][3] * hv[c][3];
         }
       ss = block_sum<GV_NW>(ss, bred);                        // waves 4.. add exact zeros: the sum of rmsnorm_fwd_kernel
@@ -285,7 +306,7 @@ __global__ __launch_bounds__(GV_NW * 64) void gemv_pro_kernel(const void* __rest
       c = 0;
       if (tid < 256)
         for (int i = tid * 4; i < K; i += 1024, ++c) {
-          const float4_t g = *reinterpret_cast<const float4_t*>(norm_w + i);
+          const float4_t g = *reinterpret_cast<const float4_t*>(norm_w + i);   // queues behind the weights: they are needed first anyway
           uint2 pk;
           pk.x = pack_bf2(g[0] * (hv[c][0] * r), g[1] * (hv[c][1] * r));
           pk.y = pack_bf2(g[2] * (hv[c][2] * r), g[3] * (hv[c][3] * r));
@@ -297,22 +318,22 @@ __global__ __launch_bounds__(GV_NW * 64) void gemv_pro_kernel(const void* __rest
   const int mrow = lr < M ? lr : M - 1;
   const bf16_t* xp = xs + (size_t)mrow * K + lg * 16;
   float4_t acc = (float4_t){0.f, 0.f, 0.f, 0.f};
-  int s = wave * per;
-  const int s0 = s;
-  const int s_end = (s + per) < nsteps ? (s + per) : nsteps;
-  for (; s + UNROLL <= s_end; s += UNROLL) {
-    short8_t w0[UNROLL], w1[UNROLL];
-#pragma unroll
-    for (int u = 0; u < UNROLL; ++u) {
-      w0[u] = __builtin_nontemporal_load(reinterpret_cast<const short8_t*>(wp + (size_t)(s - s0 + u) * 1024));
-      w1[u] = __builtin_nontemporal_load(reinterpret_cast<const short8_t*>(wp + (size_t)(s - s0 + u) * 1024 + 512));
-    }
+  while (have) {
 #pragma unroll
     for (int u = 0; u < UNROLL; ++u) {
       const int k = (s + u) * 64;
       const short8_t x0 = *reinterpret_cast<const short8_t*>(xp + k), x1 = *reinterpret_cast<const short8_t*>(xp + k + 8);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, w0[u], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w1[u], acc, 0, 0, 0);
+    }
+    s += UNROLL;
+    have = s + UNROLL <= s_end;
+    if (have) {
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u) {
+        w0[u] = __builtin_nontemporal_load(reinterpret_cast<const short8_t*>(wp + (size_t)(s - s0 + u) * 1024));
+        w1[u] = __builtin_nontemporal_load(reinterpret_cast<const short8_t*>(wp + (size_t)(s - s0 + u) * 1024 + 512));
+      }
     }
   }
   for (; s < s_end; ++s) {
@@ -353,7 +374,8 @@ static int launch_gemv_pro(const void* A, long lda, const void* P, void* C, int 
   if (M <= 0 || N <= 0) return MH_OK;
   if (M > 16 || K <= 0 || (K % 64) != 0 || ((uintptr_t)A & 15) || ((uintptr_t)P & 15)) return MH_ERR_ARG;
   if (PRO == 1 && ((K % 128) != 0 || (lda % 8) != 0 || lda < 2L * K)) return MH_ERR_ARG;
-  if (PRO == 2 && (!norm_w || (K % 4) != 0 || K > 8192 || (lda % 4) != 0)) return MH_ERR_ARG;
+  if (PRO == 2 && (!norm_w || (K % 4) != 0 || (lda % 4) != 0)) return MH_ERR_ARG;
+  if (PRO == 2 && K > 4096) return MH_ERR_UNSUPPORTED;
   const size_t sh = (size_t)M * K * 2;
   // every workgroup rebuilds all M rows: measured at batch 8 (decode, M = 8) the fused step costs 6.5 ms per token against
   // 4.1 ms with the separate launches, at batch 1 it saves 0.3 ms -- fused for up to GV_PRO_MAX_ROWS rows only

@@ -165,7 +165,7 @@ def test_decode_kernel_on_the_packed_weight_copy_is_bit_identical(M, N, K):
         ops.gemv_packed(bf(rnd(17, K)).to(DEV), pw)
 
 
-@pytest.mark.parametrize("M,N,K", [(1, 12288, 4096), (2, 4096, 4096), (2, 22016, 4096), (1, 32000, 4096), (1, 1000, 8192)])
+@pytest.mark.parametrize("M,N,K", [(1, 12288, 4096), (2, 4096, 4096), (2, 22016, 4096), (1, 32000, 4096), (1, 1000, 2048)])
 def test_decode_gemv_with_the_rmsnorm_fused_in_is_bit_identical(M, N, K):
     """mh_gemv_packed_rmsnorm: every workgroup rebuilds the normalised rows (rmsnorm_fwd_kernel's summation order and
     expression) in LDS, then streams the packed weight -- the SAME bits as mh_rmsnorm_fwd + mh_gemv_packed, with / without the

@@ -64,7 +64,8 @@ def make_samples(B: int, vocab: int, seed: int, device):
                 before_ids=before, after_ids=after, target_ids=tgt, target_mask=torch.ones(B, 16, dtype=torch.long))
 
 
-KERNEL_NAMES = {1: "gemm_nt_kernel<128x128>", 2: "gemm_256_kernel", 3: "gemm_nt_kernel<128x64>"}
+KERNEL_NAMES = {1: "gemm_nt_kernel<128x128>", 2: "gemm_256_kernel", 3: "gemm_nt_kernel<128x64>", 4: "gemm_nt_kernel<160x128>",
+                5: "gemm_nt_kernel<160x96>"}
 GEMM_OUT_F32 = 1
 
 

@@ -40,7 +40,9 @@ int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int
 
 /* Which kernel mh_gemm_bf16_nt will launch for this shape and with how many K splits (splits > 1 adds one
  * fixed-order reduce launch): *kernel = 0 weight-streaming gemv (M <= 16), 1 = 128x128x64 tile (gemm_nt_kernel),
- * 2 = 256x256x32 tile (gemm_256_kernel), 3 = gemm_nt_kernel with a 128x64 tile (grids that leave most CUs empty).
+ * 2 = 256x256x32 tile (gemm_256_kernel), 3 = gemm_nt_kernel with a 128x64 tile (grids that leave most CUs empty),
+ * 4 / 5 = gemm_nt_kernel with a 160x128 / 160x96 tile and a 4-deep ring (128 < M <= 320: the batch-1 step's 148 / 257 rows
+ * as one / two row tiles, the weight streamed once).
  * For profilers and benchmarks that attribute time per kernel. */
 int mh_gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits);
 

@@ -43,21 +43,14 @@ __device__ __forceinline__ int swz_src_chunk(int row, int phys) {
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
-  static_assert(N == 0 || N == 3 || N == 4 || N == 6 || N == 8 || N == 12 || N == 16 || N == 18 || N == 24 || N == 32, "unsupported count");
-  if (N == 18) asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-  if (N == 24) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-  if (N == 32) asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
-  if (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  if (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  if (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-  if (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-  if (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  if (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-  if (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  // s_waitcnt vmcnt(N), other counters untouched: gfx9 encoding vmcnt = simm16[15:14] : simm16[3:0], expcnt [6:4], lgkmcnt [11:8]
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit counter");
+  __builtin_amdgcn_s_waitcnt((N & 15) | 0x70 | 0xF00 | ((N >> 4) << 14));
+  asm volatile("" ::: "memory");
 }
 
 // STAGING: 0 = LDS-DMA ring (NST stages), 1 = register-staged double buffer (NST must be 2; A/B-test reference)
-template <int STAGING, int NST, int TBN, int MINB, int TBK, int NW>
+template <int STAGING, int NST, int TBN, int MINB, int TBK, int NW, int TBM>
 __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void gemm_nt_kernel(const bf16_t* __restrict__ A,
                                                             const bf16_t* __restrict__ B, void* Cv,
                                                             const float* __restrict__ bias, const float* res, int M,
@@ -69,11 +62,11 @@ __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void gemm_nt_kernel(const b
   constexpr int NJ = TBN / 32;                 // 16-wide N fragments per wave
   constexpr int NT = NW * 64;                  // threads per workgroup
   constexpr int WROWS = NW / 2;                // waves along M (x 2 along N)
-  constexpr int MI = BM / WROWS / 16;          // 16-row M fragments per wave (4 for 4 waves, 2 for 8 waves)
-  constexpr int NA = BM * CPR / NT;            // A staging chunks per thread
+  constexpr int MI = TBM / WROWS / 16;         // 16-row M fragments per wave (4 for 4 waves, 2 for 8 waves; 5 for the 160-row tile)
+  constexpr int NA = TBM * CPR / NT;           // A staging chunks per thread
   constexpr int NB = TBN * CPR / NT;           // B staging chunks per thread
   constexpr int LPT = NA + NB;                 // LDS-DMA instructions per thread per K tile
-  constexpr int A_STAGE_BYTES = BM * BK * 2;
+  constexpr int A_STAGE_BYTES = TBM * BK * 2;
   constexpr int B_STAGE_BYTES = TBN * BK * 2;
   constexpr int STAGE = A_STAGE_BYTES + B_STAGE_BYTES;
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [NST stages][A | B]
@@ -88,7 +81,7 @@ __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void gemm_nt_kernel(const b
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
   const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   const int tm = lid % tiles_m, tn = lid / tiles_m;
-  const int m0 = tm * BM, n0 = tn * TBN;
+  const int m0 = tm * TBM, n0 = tn * TBN;
 
   const bf16_t* gA[NA];
   const bf16_t* gB[NB];
@@ -259,20 +252,20 @@ struct GemmArgs {
   const float* bias; const float* residual; int ldr; int flags; float alpha; int splits, tps; long split_stride;
 };
 
-template <int STAGING, int NST, int TBN, int MINB, int TBK = 64, int NW = 4>
+template <int STAGING, int NST, int TBN, int MINB, int TBK = 64, int NW = 4, int TBM = BM>
 static int launch_gemm(const GemmArgs& g, hipStream_t stream) {
-  const int tiles_m = (g.M + BM - 1) / BM, tiles_n = (g.N + TBN - 1) / TBN;
+  const int tiles_m = (g.M + TBM - 1) / TBM, tiles_n = (g.N + TBN - 1) / TBN;
   const dim3 grid(tiles_m * tiles_n, g.splits), block(NW * 64);
-  const size_t shmem = (size_t)NST * (BM + TBN) * TBK * 2;
+  const size_t shmem = (size_t)NST * (TBM + TBN) * TBK * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<STAGING, NST, TBN, MINB, TBK, NW>,
+    (void)hipFuncSetAttribute((const void*)gemm_nt_kernel<STAGING, NST, TBN, MINB, TBK, NW, TBM>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     attr_set = true;
   }
-  if (g_mh_prof_on) mh_prof_pre(stream, TBN == 64 ? 3 : 1, g.M, g.N, g.K, g.splits, g.flags);
+  if (g_mh_prof_on) mh_prof_pre(stream, TBM == 160 ? (TBN == 96 ? 5 : 4) : (TBN == 64 ? 3 : 1), g.M, g.N, g.K, g.splits, g.flags);
   // tps / kt_per_split are in units of 64-deep K tiles at the call sites; rescale for 32-deep kernels
-  hipLaunchKernelGGL((gemm_nt_kernel<STAGING, NST, TBN, MINB, TBK, NW>), grid, block, shmem, stream, (const bf16_t*)g.A,
+  hipLaunchKernelGGL((gemm_nt_kernel<STAGING, NST, TBN, MINB, TBK, NW, TBM>), grid, block, shmem, stream, (const bf16_t*)g.A,
                      (const bf16_t*)g.B, g.C, g.bias, g.residual, g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.ldr, g.flags,
                      g.alpha, tiles_m, g.tps * (64 / TBK), g.split_stride);
   if (g_mh_prof_on) mh_prof_post(stream);
@@ -300,7 +293,8 @@ static int dispatch(const GemmArgs& g, hipStream_t stream) {
     case 9: return launch_gemm<0, 2, 128, 2, 64, 8>(g, stream);   // 8 waves/block (wave tile 32x64), 2 blocks/CU
     case 10: return launch_gemm<0, 4, 128, 1, 64, 8>(g, stream);  // 8 waves/block, 4-deep ring, 1 block/CU
     case 13: return launch_gemm<0, 6, 64, 1>(g, stream);          // 128x64, 6-deep ring (144 KiB): 5 K tiles in flight, 1 block/CU
-    case 14: return launch_gemm<0, 5, 64, 1>(g, stream);          // 128x64, 5-deep ring (120 KiB)
+    case 14: return launch_gemm<0, 4, 128, 1, 64, 4, 160>(g, stream);   // 160x128 tile, 4-deep ring (144 KiB): the M <= 160 rows of the
+    case 15: return launch_gemm<0, 4, 96, 1, 64, 4, 160>(g, stream);    // batch-1 step as ONE row tile, 160x96 (128 KiB) when N / 96 fills the chip
     case 12:                                                      // 256x256x32, 4-deep ring (gemm_256.hip), 1 block/CU
       return mh_launch_gemm_256(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, g.bias, g.residual, g.ldr, g.flags,
                                 g.alpha, g.splits, g.tps, g.split_stride, stream);
@@ -443,9 +437,14 @@ static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t str
   g.C = (void*)ws; g.ldc = g0.N; g.bias = nullptr; g.residual = nullptr; g.ldr = 0;
   g.flags = sbf ? 0 : MH_GEMM_OUT_F32; g.alpha = 1.0f; g.splits = splits; g.tps = tps; g.split_stride = (long)g0.M * g0.N;
   int rc;
+  const int var = (g0.flags >> MH_GEMM_VARIANT_SHIFT) & 15;
   if (big)
     rc = mh_launch_gemm_256(g.A, g.lda, g.B, g.ldb, g.C, g.ldc, g.M, g.N, g.K, nullptr, nullptr, 0, g.flags, 1.0f,
                             g.splits, g.tps, g.split_stride, stream);
+  else if (var == 14)
+    rc = launch_gemm<0, 4, 128, 1, 64, 4, 160>(g, stream);
+  else if (var == 15)
+    rc = launch_gemm<0, 4, 96, 1, 64, 4, 160>(g, stream);
   else
     rc = launch_gemm<0, 2, 128, 2>(g, stream);
   if (rc) return rc;
@@ -540,7 +539,7 @@ static int big_tile_splits(int M, int N, int K, int tile_n) {
 }
 
 // plan kernel id -> forced-variant number of dispatch()
-static inline int plan_variant(int kernel) { return kernel == 2 ? 12 : (kernel == 3 ? 3 : 0); }
+static inline int plan_variant(int kernel) { return kernel == 2 ? 12 : (kernel == 3 ? 3 : (kernel == 4 ? 14 : (kernel == 5 ? 15 : 0))); }
 
 // The automatic policy (flags carry no variant): which kernel runs and with how many K splits.
 //   kernel 0: gemv.hip weight streaming (M <= 16: decode)
@@ -553,12 +552,51 @@ static inline int plan_variant(int kernel) { return kernel == 2 ? 12 : (kernel =
 //             workgroup (Q-Former / VE-net shapes: 648x768 is 36 tiles).  A lone workgroup streams its operands at one
 //             CU's L2 rate (~0.5 us per 64-deep step), so twice the workgroups is twice the CUs pulling: 14 -> 10 us at
 //             K = 768, 27 -> 19 us at K = 2304 (tools/gemm_small_sweep.py); same k order per accumulator, same bits
+static int g_force_kernel = -1, g_force_splits = 0, g_skinny = -1;
+extern "C" void mhdbg_set_force_plan(int kernel, int splits) { g_force_kernel = kernel; g_force_splits = splits; }   // sweep tools
+extern "C" void mhdbg_set_skinny(int on) { g_skinny = on ? 1 : 0; }                                                 // A/B, tests
+
+// One row tile of 160 for 128 < M <= 160 (the batch-1 step's 148 LLaMA rows), two for M <= 320 (its 257 ViT rows): the
+// weight matrix is streamed ONCE (the 128-row tile reads it twice and multiplies 108 padding rows, the 256-row tile
+// multiplies 108), 160 x 96 or 160 x 128 x 64 tiles with a 4-deep ring (3 K tiles in flight per CU), K split so that the
+// launch is one round of <= 256 workgroups.  Picks the column width / split count that fills the most CUs.
+static bool skinny_plan(int M, int N, int K, bool can_split, int* kernel, int* splits) {
+  if (g_skinny < 0) { const char* e = getenv("MYRIAD_GEMM_SKINNY"); g_skinny = (e && e[0] == '0') ? 0 : 1; }
+  if (!g_skinny || M <= 128 || M > 320 || N < 512 || K < 512) return false;
+  const int tm = (M + 159) / 160;
+  int best_k = 0, best_s = 1;
+  double best_fill = 0.0;
+  for (int pass = 0; pass < 2; ++pass) {
+    const int tbn = pass ? 128 : 96;
+    const int tiles = tm * ((N + tbn - 1) / tbn);
+    int s = 256 / tiles;
+    if (!can_split || s < 1) s = 1;
+    while (s > 1 && K / s < 512) --s;
+    if (s > 16) s = 16;
+    const long wg = (long)tiles * s, rounds = (wg + 255) / 256;
+    const double fill = (double)wg / (double)(rounds * 256) * ((double)N / (double)(((N + tbn - 1) / tbn) * tbn));
+    if (fill >= best_fill - 1e-9) { best_fill = fill; best_k = pass ? 4 : 5; best_s = s; }
+  }
+  *kernel = best_k;
+  *splits = best_s;
+  return true;
+}
+
 static void gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits) {
   *kernel = 1;
   *splits = 1;
+  if (g_force_kernel >= 0) { *kernel = g_force_kernel; *splits = g_force_splits > 0 ? g_force_splits : 1; return; }
   if (M <= 16 && !(flags & (MH_GEMM_REGSTAGE | MH_GEMM_GELU))) { *kernel = 0; return; }
   if (flags & MH_GEMM_REGSTAGE) return;
   const bool can_split = g_ws && (N % 4) == 0;
+  {
+    int k2, s2;
+    if (skinny_plan(M, N, K, can_split, &k2, &s2) && (size_t)s2 * M * N * sizeof(float) <= (g_ws_bytes ? g_ws_bytes : (size_t)-1)) {
+      *kernel = k2;
+      *splits = s2;
+      return;
+    }
+  }
   if (M > 128) {
     const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
     int s = can_split ? big_tile_splits(M, N, K, 256) : 1;

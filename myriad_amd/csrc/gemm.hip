@@ -562,7 +562,8 @@ extern "C" void mhdbg_set_skinny(int on) { g_skinny = on ? 1 : 0; }             
 // launch is one round of <= 256 workgroups.  Picks the column width / split count that fills the most CUs.
 static bool skinny_plan(int M, int N, int K, bool can_split, int* kernel, int* splits) {
   if (g_skinny < 0) { const char* e = getenv("MYRIAD_GEMM_SKINNY"); g_skinny = (e && e[0] == '0') ? 0 : 1; }
-  if (!g_skinny || M <= 128 || M > 320 || N < 512 || K < 512) return false;
+  // ... for weight matrices worth streaming (>= 4 M elements): the Q-Former / VE-net shapes stay on the 128x64 tiles
+  if (!g_skinny || M <= 128 || M > 320 || N < 512 || K < 512 || (long)N * K < (4L << 20)) return false;
   const int tm = (M + 159) / 160;
   int best_k = 0, best_s = 1;
   double best_fill = 0.0;

@@ -248,6 +248,9 @@ def test_gemm_policy_for_the_steps_shapes():
         assert plan(4096, 25600, 128)[0] == 1                                            # K = 128 (VETokenizer head wgrad): 128x128 kernel
         assert plan(256, 768, 768)[0] == 3 and plan(648, 768, 2304)[0] == 3              # Q-Former sizes: 128x64 tiles fill more CUs
         assert plan(72, 4096, 25664)[0] == 1                                             # conv-stem head: 16 K splits fill the chip
+        # batch-1 step: 148 LLaMA rows / 257 ViT rows as one / two 160-row tiles, the weight streamed once, one round of workgroups
+        assert plan(148, 22016, 4096) == (5, 1) and plan(148, 12288, 4160) == (5, 2) and plan(148, 4096, 22016) == (4, 8)
+        assert plan(257, 6144, 1408) == (5, 2) and plan(129, 4096, 4096)[0] == 4 and plan(321, 4096, 4096)[0] in (1, 2)
         lib.mh_set_workspace(None, 0)
         assert plan(1184, 4096, 22016) == (1, 1)                                         # no workspace: nothing may split
         kernel, splits = ctypes.c_int(), ctypes.c_int()

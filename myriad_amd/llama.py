@@ -329,7 +329,8 @@ class LlamaHIP:
     def greedy_generate(self, inputs_embeds: torch.Tensor, max_new_tokens: int = 90,
                         stop_ids=((835,), (2277, 29937)), eos_id: int = 2, min_length: int = 1,
                         return_margins: bool = False, use_graph: bool = True, do_sample: bool = False,
-                        top_p: float = 1.0, temperature: float = 1.0, generator: Optional[torch.Generator] = None):
+                        top_p: float = 1.0, temperature: float = 1.0, generator: Optional[torch.Generator] = None,
+                        top_k: int = 50):
         """Decode from [B,S0,D] f32 embeddings with a KV cache (prefill + 1-token steps).  Same contract
         as the oracle's greedy_generate: stop when ROW 0 ends with a stop sequence (conversation.py:102-107),
         EOS banned while fewer than `min_length` tokens were generated, finished rows padded with EOS.
@@ -346,7 +347,10 @@ class LlamaHIP:
         top-p warper keeps the smallest descending-probability set whose mass reaches top_p (at least one token), so a
         step whose p_max >= top_p IS the arg-max; the kernel reports p_max per row and only a row below the threshold is
         drawn on the host from that row's logits (a genuine sample: reproducible here through `generator`, never
-        bit-comparable with another framework's RNG) and replaces the fed-back id.  `last_generate_stats` counts such steps."""
+        bit-comparable with another framework's RNG) and replaces the fed-back id.  `last_generate_stats` counts such steps.
+        The host draw applies HF's default `top_k = 50` filter first, then top-p; the device test p_max >= top_p is taken over the
+        full vocabulary, which is the conservative side: the top-k renormalisation only raises p_max, and a row whose
+        renormalised p_max reaches top_p keeps exactly one token in the host draw -- the arg-max again."""
         B, S0, D = inputs_embeds.shape
         scale = 1.0 / math.sqrt(self.hd)
         out_ids, margins = [], []
@@ -368,6 +372,8 @@ class LlamaHIP:
             lg = logits_row.float().cpu() * inv_temp
             if ban >= 0:
                 lg[ban] = float("-inf")
+            if top_k and 0 < top_k < lg.numel():                     # HF applies TopKLogitsWarper (default top_k = 50) before top-p
+                lg = lg.masked_fill(lg < torch.topk(lg, top_k).values[-1], float("-inf"))
             srt, idx = torch.sort(lg, descending=False)
             cum = srt.softmax(-1).cumsum(-1)
             remove = cum <= (1.0 - top_p)

@@ -274,6 +274,7 @@ class MyriadHIP(nn.Module):
         self._anchor = torch.zeros((), device=self._dev, requires_grad=True)
         self._ctx = None
         self._has_grads, self._bwd_gscale, self._bwd_prev = False, 1.0, None
+        self._bridge_used = set()
 
     # ------------------------------------------------------------------ nn.Module plumbing
     def _register_dotted(self, name: str, prm: nn.Parameter):
@@ -551,6 +552,9 @@ class MyriadHIP(nn.Module):
         else:
             used.add("llama_proj")
         self.store.mark_used(used)
+        # modules whose parameters receive a gradient in this accumulation window (the bridge path hands torch's optimiser
+        # `.grad is None` for the others, exactly what autograd leaves for a module the forward never touched)
+        self._bridge_used = (self._bridge_used | used) if accumulate else set(used)
         self._bwd_gscale, self._bwd_prev = float(gscale), prev
         demb = self.llama.backward(defer_lora_join=True)              # [B,S,Dl] f32; LoRA wgrads run on a side stream
         self._prefetch_vit_rest()                                     # the look-ahead's second piece: beside the light tail of the step
@@ -613,9 +617,15 @@ class MyriadHIP(nn.Module):
         self._ctx = None
 
     def _reattach_grads(self):
-        # the reference loop calls optimizer.zero_grad() (set_to_none) -- keep .grad aliased to the flat buffer
+        """Autograd-bridge path (`model(samples)["loss"].backward()` + an external torch optimiser): `.grad` aliases the flat
+        buffer for the parameters of modules this step (or accumulation window) used, and is None for the others -- a module
+        unused at this prompt stage (VEInstructor at stage 0, VETokenizer at stage 2; myriad.py:378,252,265) then gets no
+        weight decay, no moment decay and no step increment from torch.optim.AdamW, as in the reference."""
+        used = getattr(self, "_bridge_used", None)
         for name, prm in self._params.items():
-            if prm.grad is None or prm.grad.data_ptr() != self.store.g[name].data_ptr():
+            if used is not None and module_of(name) not in used:
+                prm.grad = None
+            elif prm.grad is None or prm.grad.data_ptr() != self.store.g[name].data_ptr():
                 prm.grad = self.store.g[name]
 
     def _side_stream(self, name: str):
@@ -802,10 +812,11 @@ class MyriadHIP(nn.Module):
         kw.pop("pad_token_id", None)
         if not kw.pop("use_cache", True):
             raise NotImplementedError("use_cache=False: decode here always keeps a KV cache (same tokens)")
-        for k, neutral in (("num_beams", 1), ("repetition_penalty", 1.0), ("length_penalty", 1), ("top_k", 0),
-                           ("num_return_sequences", 1)):
+        top_k = kw.pop("top_k", 50)                         # HF's generation default; only a sampled (host-drawn) row sees it
+        top_k = 0 if top_k is None else int(top_k)
+        for k, neutral in (("num_beams", 1), ("repetition_penalty", 1.0), ("length_penalty", 1), ("num_return_sequences", 1)):
             v = kw.pop(k, neutral)
-            if v not in (neutral, None) and not (k == "top_k" and not do_sample):
+            if v not in (neutral, None):
                 raise NotImplementedError(f"generate({k}={v}) is not implemented on the HIP decode path")
         generator = kw.pop("generator", None)
         if kw:
@@ -823,7 +834,8 @@ class MyriadHIP(nn.Module):
         if max_new is None:
             max_new = max(1, max_len - emb.shape[1])
         ids = self.llama.greedy_generate(emb, max_new_tokens=max_new, stop_ids=stops, min_length=min_length, eos_id=eos_id,
-                                         do_sample=do_sample, top_p=top_p, temperature=temperature, generator=generator)
+                                         do_sample=do_sample, top_p=top_p, temperature=temperature, generator=generator,
+                                         top_k=top_k)
         self.last_generate_stats = self.llama.last_generate_stats
         return {"token_ids": ids, "ve_anomaly_maps": maps}
 

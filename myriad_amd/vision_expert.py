@@ -128,7 +128,8 @@ class VisionExpertHIP:
         _, taps = self.trunk.forward(images.to(self.dev, F32))
         return self._zero_shot_from_taps(taps, text_feats)
 
-    def _zero_shot_from_taps(self, taps, text_feats):
+    def _zero_shot_from_taps(self, taps, text_feats, keep_logits=None):
+        """`keep_logits`: a list that receives each tap's pair logits [B*L, 2] (100 * cosine; tests compare these)."""
         B, N, D = taps[0].shape
         L = N - 1
         h = int(round(L ** 0.5))
@@ -142,6 +143,8 @@ class VisionExpertHIP:
             for i in range(B):                                                        # patch rows only: class token dropped
                 ops.gemm(tok[i * N + 1:(i + 1) * N], w, bias=b, out=p[i * L:(i + 1) * L])   # image_decoder.fc[tap]
             logits = ops.pair_logits(p, text, L, 100.0)                               # 100 * cos(p, text)
+            if keep_logits is not None:
+                keep_logits.append(logits.clone())
             ops.zs_accumulate(logits, mask, amap, 1.0 / len(taps))
         return amap.view(B, 1, S, S), mask.view(B, 1, h, h)
 

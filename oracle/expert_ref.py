@@ -81,6 +81,17 @@ def vision_trunk(sd: Dict[str, torch.Tensor], image: torch.Tensor, heads: int, o
     return e / e.norm(dim=-1, keepdim=True), taps
 
 
+def zero_shot_logits(taps: List[torch.Tensor], decoder_sd: Dict[str, torch.Tensor], text_feats: torch.Tensor) -> List[torch.Tensor]:
+    """The pair logits 100 * cos(decoded patch, [normal, abnormal] text) of adrefexpert_v2.py:277-289, per tap: [B, L, 2].
+    (What zero_shot_maps soft-maxes; tests compare these, where a cosine error is not amplified through the softmax.)"""
+    out = []
+    for i, t in enumerate(taps):
+        p = t[:, 1:].float() @ decoder_sd[f"fc.{i}.weight"].float().t() + decoder_sd[f"fc.{i}.bias"].float()
+        p = p / p.norm(dim=-1, keepdim=True)
+        out.append(100.0 * p @ text_feats.float().transpose(-2, -1))
+    return out
+
+
 def zero_shot_maps(taps: List[torch.Tensor], decoder_sd: Dict[str, torch.Tensor], text_feats: torch.Tensor,
                    out_size: int = 224) -> Tuple[torch.Tensor, torch.Tensor]:
     """adrefexpert_v2.py:277-301.  taps [B, 1+L, D]; decoder_sd keys `fc.{i}.weight/bias`; text_feats [B, 2, C]

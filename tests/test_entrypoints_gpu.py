@@ -161,6 +161,32 @@ def test_unused_modules_are_skipped_like_torch_adamw(model):
         model.fixed_stage, model.fixed_taskstage = saved
 
 
+def test_bridge_path_leaves_unused_modules_without_a_gradient(model):
+    """The autograd-bridge path -- `model(samples)["loss"].backward()` with an external torch.optim.AdamW, what RunnerBase uses
+    for accum_grad_iters > 1 -- hands torch `.grad is None` for a module the step did not use, so AdamW applies neither weight
+    decay nor a step to it (the reference: autograd never touches VEInstructor at prompt stage 0)."""
+    samples = _batch(2, train=True, seed=12)
+    model.train()
+    saved = (model.fixed_stage, model.fixed_taskstage)
+    try:
+        model.fixed_stage, model.fixed_taskstage = 0, 0
+        params = dict(model.named_parameters())
+        opt = torch.optim.AdamW([p for p in params.values() if p.requires_grad], lr=1e-3, weight_decay=0.05)
+        before = {n: p.detach().clone() for n, p in params.items()}
+        opt.zero_grad(set_to_none=True)
+        model(samples)["loss"].backward()
+        none = {n for n, p in params.items() if p.requires_grad and p.grad is None}
+        assert none and all(n.startswith("VEInstructor.") for n in none)
+        assert all(params[n].grad is not None for n in params if n.startswith(("VETokenizer.", "expert_adaptor.")))
+        opt.step()
+        torch.cuda.synchronize()
+        for n, p in params.items():
+            if p.requires_grad:
+                assert torch.equal(p.detach(), before[n]) == n.startswith("VEInstructor."), n
+    finally:
+        model.fixed_stage, model.fixed_taskstage = saved
+
+
 def test_checkpoint_round_trip_on_the_real_model(model, fx, tmp_path):
     """runner_base.py:592-672 on the HIP model: two training steps, CheckpointManager.save, a FRESH model built from the same
     files + that checkpoint, identical loss and identical next step (parameters, moments, per-module step counts)."""

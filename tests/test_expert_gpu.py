@@ -71,6 +71,13 @@ def test_vision_expert_full_depth_vs_oracle():
     for i, e in enumerate(errs):
         assert e < 2e-2, (i, e)                                   # activations: 2e-2 of max-abs (measured 5e-3 at full depth)
     assert (emb.cpu() - emb_o).abs().max() < 2e-2                # unit vectors
+    # the zero-shot head compared where nothing amplifies the error: the pair logits 100 * cos(patch, text) per tap, in units
+    # of the cosine (|d cos| <= 3e-3 at full depth; the maps below push the same error through a softmax of slope 25)
+    kept = []
+    ex._zero_shot_from_taps(taps, text, keep_logits=kept)
+    for lg, lo in zip(kept, X.zero_shot_logits(taps_o, dec, text)):
+        assert lg.shape[1] == 2 and lg.shape[0] == lo.shape[0] * lo.shape[1]
+        assert float((lg.cpu().view_as(lo) - lo).abs().max()) / 100.0 < 3e-3
     (zmap, zmask), (omap, omask) = ex.forward(images, text, refs)
     assert (zmap.cpu() - zmap_o).abs().max() < 1e-1 and (zmap.cpu() - zmap_o).abs().mean() < 1e-2
     assert (zmask.cpu() - zmask_o).abs().max() < 1e-1

@@ -98,6 +98,28 @@ def test_benchmark_shape_b8_is_deterministic_and_batch_independent(model):
     assert cos >= 0.995, cos
 
 
+def test_bf16_split_k_slabs_stay_inside_the_stated_tolerances(model):
+    """The 256x256 kernel hands its split-K partial sums over as bf16 slabs (each partial rounded once, 2^-9) -- also where
+    the consumer writes the fp32 residual stream or an fp32 gradient (gemm.hip run_splitk; MYRIAD_SLAB_BF16=0 keeps fp32).
+    Full-size model at the bench shape, same batch, both slab types: the loss moves by < 1e-3 relative and the 115 M
+    gradients stay within the tolerance the gradients carry against the fp32 oracle anyway (5e-2 of max-abs, cosine >= 0.999)."""
+    from myriad_amd import _lib
+    lib = _lib.load()
+    s = samples(8, seed=23)
+    try:
+        lib.mhdbg_set_slab_bf16(0)
+        l32, g32 = loss_and_grad(model, s)
+        lib.mhdbg_set_slab_bf16(1)
+        l16, g16 = loss_and_grad(model, s)
+    finally:
+        lib.mhdbg_set_slab_bf16(1)
+    assert l32 != l16                                             # the switch does reach the kernels
+    assert abs(l16 - l32) < 1e-3 * abs(l32), (l16, l32)
+    assert float((g16 - g32).abs().max()) < 5e-2 * float(g32.abs().max())
+    cos = float((g16.double() @ g32.double()) / (g16.double().norm() * g32.double().norm()))
+    assert cos >= 0.999, cos
+
+
 def test_benchmark_shape_b8_train_step_with_lora_dropout(model):
     """One full optimisation step at the bench shape with `use_lora` and peft's dropout (p = 0.05) ON: finite, repeatable
     from the same state and step seed, the dropout changes the loss, and the LoRA / adapter parameters move."""

@@ -227,6 +227,86 @@ def test_exchange_modes_world2_gloo():
             assert torch.equal(got[0][key][3], got[1][key][3])        # every rank ends with the same parameters
 
 
+def _dp_world4_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    specs = [("expert_adaptor.conv1.weight", (4, 1408), (4, 1408)), ("VETokenizer.base_prompts", (9, 4096), (9, 4096)),
+             ("VEInstructor.meta_net.0.bias", (4,), (4,)), ("VEInstructor.meta_net.15.weight", (768, 1024, 1, 1), (768, 1024, 1, 1)),
+             ("llama_model.base_model.model.model.layers.0.self_attn.q_proj.lora_A.default.weight", (8, 4096), (8, 4096))]
+    out = {}
+    # ragged use: the prompt stage is drawn per rank (myriad.py:378): tokenizer on ranks 0 and 3, instructor on rank 1 only,
+    # adaptor everywhere, LoRA nowhere
+    used_by_rank = [{"expert_adaptor", "VETokenizer"}, {"expert_adaptor", "VEInstructor"}, {"expert_adaptor"},
+                    {"expert_adaptor", "VETokenizer"}]
+    for mode in ("allreduce", "rs_ag"):
+        st = ParamStore(specs, "cpu")
+        assert st.total % 32 == 0 and st.total >= st.n_used       # padded once: every shard of 2 / 4 / 8 ranks tiles it exactly
+        torch.manual_seed(50 + rank)
+        st.flat_g[:st.n_used].copy_(torch.randn(st.n_used))
+        for name, _, _ in st.specs:                               # an unused module contributes an exact zero gradient
+            from myriad_amd.myriad import module_of
+            if module_of(name) not in used_by_rank[rank]:
+                st.g[name].zero_()
+        flags = torch.tensor([1.0 if m in used_by_rank[rank] else 0.0 for m in st.modules])
+        st.used.copy_(flags)
+        mine = st.flat_g.clone()
+        dp = DataParallel(device=None, mode=mode)
+        n_alloc0 = len(dp._bufs)
+        for _ in range(2):                                        # two exchanges: the staging buffers are allocated once
+            st.flat_g.copy_(mine)
+            st.used.copy_(flags)
+            dp.allreduce(st.flat_g_comm, st.total)
+        lo, hi, per = dp.shard(st.total)
+        assert per * world == st.total
+        p = torch.zeros(st.total)
+        if mode == "rs_ag":
+            p[lo:hi] = -st.flat_g[lo:hi]
+            dp.gather_params(p)
+            st.moments_complete = False
+            dp.gather_state(st)
+            assert st.moments_complete
+        out[mode] = (mine.numpy().copy(), st.flat_g.numpy().copy(), st.used.numpy().copy(), p.numpy().copy(), (lo, hi),
+                     len(dp._bufs) - n_alloc0, list(st.modules))
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_exchange_world4_gloo_with_ragged_module_use():
+    """Four ranks, each with its own prompt stage: the per-module use flags are summed by the same exchange that sums the
+    gradients (all-reduce) or ride beside it (reduce-scatter + all-gather); the padded flat buffer needs no per-step
+    concatenation, and the staging buffers of `rs_ag` are allocated once."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_world4_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for mode in ("allreduce", "rs_ag"):
+        mine = [torch.from_numpy(got[r][mode][0]) for r in range(world)]
+        total = sum(mine)
+        modules = got[0][mode][6]
+        want_flags = [4.0 if m == "expert_adaptor" else 2.0 if m == "VETokenizer" else 1.0 if m == "VEInstructor" else 0.0 for m in modules]
+        for r in range(world):
+            _, red, used, p, (lo, hi), n_new, _ = got[r][mode]
+            red, p = torch.from_numpy(red), torch.from_numpy(p)
+            assert used.tolist() == want_flags, (mode, r, used)
+            if mode == "allreduce":
+                assert torch.allclose(red, total, atol=1e-5) and n_new == 0
+            else:
+                assert torch.allclose(red[lo:hi], total[lo:hi], atol=1e-5)
+                assert torch.allclose(p, -total, atol=1e-5)
+                assert n_new <= 1                                     # gloo path: one persistent staging buffer for the all-gather
+        if mode == "rs_ag":
+            assert all(np.array_equal(got[0][mode][3], got[r][mode][3]) for r in range(1, world))
+
+
 def test_gemm_policy_for_the_steps_shapes():
     """mh_gemm_plan is host-only logic (no launch): which kernel / how many K splits the library picks.  Pins the
     policy for the shapes of the fine-tune step (B*S = 1184 LLaMA rows, 2056 ViT rows) and the decode token."""

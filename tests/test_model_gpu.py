@@ -129,6 +129,9 @@ def test_top_p_sampling_falls_back_to_a_real_draw_on_flat_logits():
     assert torch.equal(a, b)                                                    # reproducible through the generator
     greedy = lm.greedy_generate(emb, max_new_tokens=6, stop_ids=())
     assert lm.last_generate_stats["sampled_rows"] == 0 and greedy.shape == a.shape
+    # HF's TopKLogitsWarper runs before top-p (default top_k = 50): with top_k = 1 every host draw can only return the arg-max
+    k1 = lm.greedy_generate(emb, max_new_tokens=6, stop_ids=(), do_sample=True, top_p=0.9, top_k=1, generator=torch.Generator().manual_seed(7))
+    assert lm.last_generate_stats["sampled_rows"] > 0 and torch.equal(k1, greedy)
 
 
 def test_llama_fullwidth_loss_and_input_grad_vs_golden():

@@ -232,7 +232,10 @@ def test_composite_step_vs_golden(composite, arch, stage):
         w0 = grads["VEInstructor.meta_net.0.weight"].reshape(4, 3, 3, 1).permute(0, 3, 1, 2)
         assert stem_grad_close(w0, g[key + "_instr_dw0"])
     else:
-        assert float(grads["VEInstructor.meta_net.15.weight"].abs().max()) == 0     # unused => zero (DDP semantics)
+        # unused at this prompt stage: no gradient for torch's optimiser (autograd leaves None in the reference), zeros in the flat
+        # buffer that the data-parallel exchange sums
+        assert grads["VEInstructor.meta_net.15.weight"] is None
+        assert float(model.store.g["VEInstructor.meta_net.15.weight"].abs().max()) == 0
     if stage in (0, 1):
         w15 = grads["VETokenizer.meta_net.15.weight"]
         assert abs(w15.norm().item() - g[key + "_tok_dw15_norm"].item()) < 5e-2 * g[key + "_tok_dw15_norm"].item()
@@ -240,7 +243,8 @@ def test_composite_step_vs_golden(composite, arch, stage):
         assert stem_grad_close(w0, g[key + "_tok_dw0"])
         assert relerr(grads["VETokenizer.base_prompts"][:, ::64], g[key + "_tok_dbase_sub"]) < 5e-2
     else:
-        assert float(grads["VETokenizer.meta_net.15.weight"].abs().max()) == 0
+        assert grads["VETokenizer.meta_net.15.weight"] is None
+        assert float(model.store.g["VETokenizer.meta_net.15.weight"].abs().max()) == 0
 
 
 def test_networks_vs_golden():

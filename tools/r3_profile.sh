@@ -4,7 +4,30 @@
 #   between the two marker kernels first) + main-stream gaps; three PMC passes (MFMA busy, FETCH_SIZE, WRITE_SIZE; each with
 #   --kernel-trace only) -> per-kernel table + per-launch-grid traffic of the dominant kernel; decode bench + trace.
 R=$(pwd); O=$R/gpurun_out/${1:-r3p}; mkdir -p $O
-BENCH_SHAPES=$O/step_gemm_shapes.csv python bench.py > $O/bench.log 2>&1; tail -1 $O/bench.log > $O/bench_n1.json
+# clocks and socket power WHILE the bench runs (one rocm-smi sample per 0.5 s, in the background; the DVFS ceiling under matrix load)
+( for i in $(seq 1 90); do rocm-smi --showclocks --showpower --json 2>/dev/null | tr -d '\n'; echo; sleep 0.5; done ) > $O/smi_during_bench.jsonl &
+SMI=$!
+BENCH_SHAPES=$O/step_gemm_shapes.csv python bench.py --steps 60 --warmup 3 > $O/bench.log 2>&1; tail -1 $O/bench.log > $O/bench_n1.json
+kill $SMI 2>/dev/null
+python - <<PY > $O/smi_during_bench.md
+import json
+sc, pw = [], []
+for ln in open("$O/smi_during_bench.jsonl"):
+    try:
+        d = json.loads(ln)
+    except Exception:
+        continue
+    for card in d.values():
+        for k, v in card.items():
+            if "sclk" in k and "MHz" in str(v).replace("Mhz", "MHz"):
+                sc.append(int("".join(c for c in str(v).split("(")[-1] if c.isdigit())))
+            if "Power" in k and "W" in k:
+                try: pw.append(float(v))
+                except Exception: pass
+print("rocm-smi sampled every 0.5 s while python bench.py --steps 60 ran (model build, warm-up, 60 timed steps, probe, batch-1 line, cpu baseline)")
+if sc: print(f"sclk MHz: samples {len(sc)}, max {max(sc)}, sorted tail {sorted(sc)[-8:]}")
+if pw: print(f"socket power W: samples {len(pw)}, max {max(pw):.0f}, sorted tail {[round(x) for x in sorted(pw)[-8:]]}")
+PY
 cd /tmp && export TMPDIR=/tmp
 BENCH_SHAPES=$O/step_gemm_shapes_profiled.csv timeout 900 rocprofv3 --kernel-trace -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline > $O/kt.log 2>&1
 timeout 600 rocprofv3 --kernel-trace -d $O/ktdec -o dec -- python $R/tools/decode_bench.py --new 96 > $O/ktdec.log 2>&1

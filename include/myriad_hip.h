@@ -256,6 +256,21 @@ int mh_gemv_packed_rmsnorm(const float* H, long ldh, const float* norm_w, float 
                            mh_stream_t s);
 int mh_gemv_packed_silu(const void* gu, long ldgu, const void* P, void* C, int ldc, int M, int N, int K, const float* bias,
                         const float* residual, int ldr, int out_f32, float alpha, mh_stream_t s);
+/* The whole token step of the decoder in ONE persistent launch (modeling_llama.py:184-299,564-604 with the KV cache) for 1-2
+ * rows: per layer RMSNorm + q|k|v, rotary + KV append + attention, o_proj + residual, RMSNorm + gate|up, SiLU gate + down +
+ * residual, then the final RMSNorm + lm_head -> logits [M, V] f32.  One 8-wave workgroup per CU, phases separated by a grid
+ * barrier (agent-scope release / counter / acquire); before each barrier every wave requests the first 16 KiB of its next
+ * phase's weights, so the HBM stream does not drain at phase boundaries the way it does at launch boundaries.  Bit-identical
+ * to the separate launches.  layers: device array of n_layers records of 7 pointers {wqkv, wo, wgu, wd (mh_gemv_pack copies),
+ * ln1, ln2 (f32), cache [B][T_cap][2D] bf16}; h: the embedded token on entry, the residual stream after (h2 its twin);
+ * qkv / o / gu: scratch [M, 3D] / [M, D] / [M, 2I] bf16; bar: two zeroed uint32 owned by the caller ([1] is raised if a
+ * barrier ever times out: the step is then invalid); n_wg: workgroups = CUs certainly free (all must be resident).
+ * MH_ERR_UNSUPPORTED outside M <= 2, head_dim 128, D <= 4096 (multiple of 1024), I % 128 == 0, LLaMA-7B-like block counts. */
+long mh_decode_mega_lds_bytes(int M, int D, int I, int T_cap);
+int mh_decode_mega(const void* layers, int n_layers, int M, int D, int H, int hd, int I, int V, int T_cap, float eps,
+                   float scale, float* h, float* h2, void* qkv, void* o, void* gu, const float* norm, const void* lm_head,
+                   float* logits, const int* pos, const int* pos_dev, const int* kvlen, const float* cos_tab,
+                   const float* sin_tab, long cache_bstride, long ld_cache, void* bar, int n_wg, mh_stream_t s);
 /* One decode token of attention (modeling_llama.py:186-222 with the KV cache): rotary on q / k, k | v appended at cache row
  * pos_dev[0], the one query against kv_len[b] keys -- mh_rope_kv_append + mh_attn_fwd(Sq = 1) in one launch, same bits.
  * qkv [B, ld_qkv] bf16 = [q | k | v] (q rotated in place), cache [B][T_cap][2 H D] rows [k | v], out [B, H D] bf16. */

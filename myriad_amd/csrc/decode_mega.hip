@@ -56,7 +56,9 @@ struct MegaParams {
   long cache_bs;
   int ld_cache;
   unsigned* bar;               // [0] arrival counter (zeroed by mg_reset_kernel in front of every launch), [1] abort flag (sticky)
+  long long* trace;            // debug: workgroup 0 stamps the 100 MHz counter at every phase boundary of layer 1 (NULL: off)
 };
+#define MG_STAMP(i) if (p.trace && li == 1 && blockIdx.x == 0 && threadIdx.x == 0) p.trace[i] = (long long)__builtin_amdgcn_s_memrealtime();
 
 struct MgBatch { short8_t w0[MG_U], w1[MG_U]; };
 
@@ -64,20 +66,22 @@ struct MgBatch { short8_t w0[MG_U], w1[MG_U]; };
 // requests the next phase's weights, then wait (relaxed polling, one acquire).  The release drains the wave's vector-memory
 // counter, so the weight requests must come AFTER it -- otherwise arriving would wait for them. ------------------------------
 __device__ __forceinline__ void mg_arrive(unsigned* bar, unsigned& target, int nwg) {
+  // every cross-workgroup output of a phase is written with agent-scope (write-through, `sc1`) stores, so publishing it needs
+  // no L2 write-back fence (6-17 us per barrier measured with one): each wave drains its own stores, then lane 0 counts in
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   target += (unsigned)nwg;
 }
+__device__ __forceinline__ void mg_store_f32(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mg_store_u16(bf16_t* p, bf16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mg_store_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ __forceinline__ void mg_wait(unsigned* bar, unsigned target) {
   if (threadIdx.x == 0) {
     unsigned spins = 0;
     while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-      __builtin_amdgcn_s_sleep(1);
-      if (++spins > (1u << 24)) {                           // ~seconds: a workgroup never arrived -- give up instead of hanging
+      __builtin_amdgcn_s_sleep(2);
+      if (++spins > (1u << 23)) {                           // ~seconds: a workgroup never arrived -- give up instead of hanging
         __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         break;
       }
@@ -179,8 +183,8 @@ __device__ __forceinline__ void mg_gemv(const bf16_t* P, int N, int K, const bf1
           for (int w = 0; w < NWP; ++w) v += red[(wave + w) * 256 + m * 16 + lr];
           v *= 1.0f;
           if (res) v += res[(size_t)m * ldr + n];
-          if (out_f32) reinterpret_cast<float*>(Cv)[(size_t)m * ldc + n] = v;
-          else reinterpret_cast<bf16_t*>(Cv)[(size_t)m * ldc + n] = f2bf(v);
+          if (out_f32) mg_store_f32(reinterpret_cast<float*>(Cv) + (size_t)m * ldc + n, v);
+          else mg_store_u16(reinterpret_cast<bf16_t*>(Cv) + (size_t)m * ldc + n, f2bf(v));
         }
       }
     }
@@ -365,7 +369,7 @@ __device__ __forceinline__ void mg_attention(const MegaParams& p, const MegaLaye
       r0 += part[w * 128 + 2 * lane];
       r1 += part[w * 128 + 2 * lane + 1];
     }
-    *reinterpret_cast<unsigned*>(p.o + (size_t)b * W + h * D + 2 * lane) = pack_bf2(r0 * inv, r1 * inv);
+    mg_store_u32(reinterpret_cast<unsigned*>(p.o + (size_t)b * W + h * D + 2 * lane), pack_bf2(r0 * inv, r1 * inv));
   }
   __syncthreads();
 }
@@ -389,40 +393,57 @@ __global__ __launch_bounds__(MG_NT, 2) void decode_mega_kernel(MegaParams p) {
   for (int li = 0; li < p.n_layers; ++li) {
     const MegaLayer L = p.layers[li];
     // P1: q | k | v
+    MG_STAMP(0)
     mg_rows_rmsnorm(h, L.ln1, M, D, p.eps, xs, bred);
+    MG_STAMP(1)
     mg_gemv<4>(L.wqkv, 3 * D, D, xs, M, red, p.qkv, 3 * D, 0, nullptr, 0, g, G, b);
+    MG_STAMP(2)
     mg_arrive(p.bar, target, G);
     mg_prefetch<8>(L.wo, D, D, g, b);                      // all of o_proj: 16 KiB per wave
     mg_wait(p.bar, target);
+    MG_STAMP(3)
     // P2: rotary + append + attention, one (row, head) per workgroup
     for (int unit = g; unit < M * p.H; unit += G) mg_attention(p, L, unit, sc, part);
+    MG_STAMP(4)
     mg_arrive(p.bar, target, G);
     mg_wait(p.bar, target);
+    MG_STAMP(5)
     // P3: o_proj + residual
     mg_rows_copy(p.o, M, D, xs);
     mg_gemv<8>(L.wo, D, D, xs, M, red, h2, D, 1, h, D, g, G, b);
+    MG_STAMP(6)
     mg_arrive(p.bar, target, G);
     mg_prefetch<4>(L.wgu, 2 * I, D, g, b);
     mg_wait(p.bar, target);
+    MG_STAMP(7)
     // P4: gate | up
     mg_rows_rmsnorm(h2, L.ln2, M, D, p.eps, xs, bred);
+    MG_STAMP(8)
     mg_gemv<4>(L.wgu, 2 * I, D, xs, M, red, p.gu, 2 * I, 0, nullptr, 0, g, G, b);
+    MG_STAMP(9)
     mg_arrive(p.bar, target, G);
     mg_prefetch<8>(L.wd, D, I, g, b);
     mg_wait(p.bar, target);
+    MG_STAMP(10)
     // P5: SiLU gate + down projection + residual
     mg_rows_silu(p.gu, M, I, xs);
+    MG_STAMP(11)
     mg_gemv<8>(L.wd, D, I, xs, M, red, h, D, 1, h2, D, g, G, b);
+    MG_STAMP(12)
     mg_arrive(p.bar, target, G);
     if (li + 1 < p.n_layers) mg_prefetch<4>(p.layers[li + 1].wqkv, 3 * D, D, g, b);
     else mg_prefetch<4>(p.lm_head, p.V, D, g, b);
     mg_wait(p.bar, target);
+    MG_STAMP(13)
   }
   mg_rows_rmsnorm(h, p.norm, M, D, p.eps, xs, bred);
   mg_gemv<4>(p.lm_head, p.V, D, xs, M, red, p.logits, p.V, 1, nullptr, 0, g, G, b);
 }
 
 __global__ void mg_reset_kernel(unsigned* bar) { bar[0] = 0u; }
+
+static long long* g_mega_trace = nullptr;
+extern "C" void mhdbg_set_mega_trace(void* ptr) { g_mega_trace = (long long*)ptr; }   // debug hook, not part of the ABI
 
 extern "C" long mh_decode_mega_lds_bytes(int M, int D, int I, int T_cap) {
   const int KX = I > D ? I : D;
@@ -452,7 +473,7 @@ extern "C" int mh_decode_mega(const void* layers, int n_layers, int M, int D, in
   p.layers = (const MegaLayer*)layers; p.n_layers = n_layers; p.M = M; p.D = D; p.H = H; p.hd = hd; p.I = I; p.V = V; p.T_cap = T_cap;
   p.eps = eps; p.scale = scale; p.h = h; p.h2 = h2; p.qkv = (bf16_t*)qkv; p.o = (bf16_t*)o; p.gu = (bf16_t*)gu; p.norm = norm;
   p.lm_head = (const bf16_t*)lm_head; p.logits = logits; p.pos = pos; p.pos_dev = pos_dev; p.kvlen = kvlen; p.cs = cos_tab; p.sn = sin_tab;
-  p.cache_bs = cache_bstride; p.ld_cache = (int)ld_cache; p.bar = (unsigned*)bar;
+  p.cache_bs = cache_bstride; p.ld_cache = (int)ld_cache; p.bar = (unsigned*)bar; p.trace = g_mega_trace;
   const size_t sh = (size_t)mh_decode_mega_lds_bytes(M, D, I, T_cap);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)decode_mega_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }

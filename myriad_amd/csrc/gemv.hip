@@ -80,13 +80,24 @@ __global__ __launch_bounds__(GV_NW * 64) void gemv_kernel(const bf16_t* __restri
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1[u], w1[u], acc, 0, 0, 0);
       }
     }
-    for (; s < s_end; ++s) {
-      const int k = s * 64;
-      const short8_t w0 = *reinterpret_cast<const short8_t*>(wp + (size_t)(s - s0) * 1024);
-      const short8_t w1 = *reinterpret_cast<const short8_t*>(wp + (size_t)(s - s0) * 1024 + 512);
-      const short8_t x0 = *reinterpret_cast<const short8_t*>(xp + k), x1 = *reinterpret_cast<const short8_t*>(xp + k + 8);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, w0, acc, 0, 0, 0);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w1, acc, 0, 0, 0);
+    if (s < s_end) {                                   // remainder as one partial batch (loads in flight together), same order
+      const int rem = s_end - s;
+      short8_t w0[UNROLL], w1[UNROLL], x0[UNROLL], x1[UNROLL];
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+        if (u < rem) {
+          const int k = (s + u) * 64;
+          w0[u] = __builtin_nontemporal_load(reinterpret_cast<const short8_t*>(wp + (size_t)(s - s0 + u) * 1024));
+          w1[u] = __builtin_nontemporal_load(reinterpret_cast<const short8_t*>(wp + (size_t)(s - s0 + u) * 1024 + 512));
+          x0[u] = *reinterpret_cast<const short8_t*>(xp + k);
+          x1[u] = *reinterpret_cast<const short8_t*>(xp + k + 8);
+        }
+#pragma unroll
+      for (int u = 0; u < UNROLL; ++u)
+        if (u < rem) {
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0[u], w0[u], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1[u], w1[u], acc, 0, 0, 0);
+        }
     }
   } else {
     // 64-deep steps, lane holds k = 16*lg .. 16*lg+15 (32 contiguous bytes); wave w owns the contiguous K quarter
@@ -336,13 +347,24 @@ __global__ __launch_bounds__(GV_NW * 64) void gemv_pro_kernel(const void* __rest
       }
     }
   }
-  for (; s < s_end; ++s) {
-    const int k = s * 64;
-    const short8_t w0 = *reinterpret_cast<const short8_t*>(wp + (size_t)(s - s0) * 1024);
-    const short8_t w1 = *reinterpret_cast<const short8_t*>(wp + (size_t)(s - s0) * 1024 + 512);
-    const short8_t x0 = *reinterpret_cast<const short8_t*>(xp + k), x1 = *reinterpret_cast<const short8_t*>(xp + k + 8);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, w0, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w1, acc, 0, 0, 0);
+  if (s < s_end) {
+    // the remainder of this wave's K range (K = 11008: 22 steps = 2 batches + 6) as ONE partial batch: its loads fly together
+    // instead of one load latency per step; same accumulation order
+    const int rem = s_end - s;
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+      if (u < rem) {
+        w0[u] = __builtin_nontemporal_load(reinterpret_cast<const short8_t*>(wp + (size_t)(s - s0 + u) * 1024));
+        w1[u] = __builtin_nontemporal_load(reinterpret_cast<const short8_t*>(wp + (size_t)(s - s0 + u) * 1024 + 512));
+      }
+#pragma unroll
+    for (int u = 0; u < UNROLL; ++u)
+      if (u < rem) {
+        const int k = (s + u) * 64;
+        const short8_t x0 = *reinterpret_cast<const short8_t*>(xp + k), x1 = *reinterpret_cast<const short8_t*>(xp + k + 8);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x0, w0[u], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(x1, w1[u], acc, 0, 0, 0);
+      }
   }
 #pragma unroll
   for (int r = 0; r < 4; ++r) red[wave][(4 * lg + r) * 16 + lr] = acc[r];

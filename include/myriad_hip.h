@@ -5,10 +5,11 @@
  * checkout).  The drop-in boundary one level up is the registered model class (myriad_amd.Myriad / MiniGPT4).
  *
  * Conventions: plain device pointers owned by the caller, explicit dims / leading
- * dimensions in ELEMENTS, explicit hipStream_t, no hidden allocation (workspaces are passed in).  The only
- * process-global state is what the caller registers: the split-K scratch of mh_set_workspace / mh_set_stream_workspace
- * (one per stream that may split K: two streams must not share one) and a few switches read once from the
- * environment (MYRIAD_SLAB_BF16, MYRIAD_SWIGLU_FUSED).  Calls on different streams with their own scratch are independent.
+ * dimensions in ELEMENTS, explicit hipStream_t, no hidden allocation (workspaces are passed in).  Library state is what
+ * the caller registers: the split-K scratch -- in an opaque mh_ctx (mh_ctx_set_workspace + mh_ctx_make_current) or in the
+ * process-default record (mh_set_workspace / mh_set_stream_workspace); one scratch per stream that may split K: two streams
+ * must not share one -- plus a few switches read once from the environment (MYRIAD_SLAB_BF16, MYRIAD_SWIGLU_FUSED).
+ * Calls on different streams with their own scratch are independent.
  * Every function returns 0 on success or a negative MH_ERR_* code and never throws.
  * bf16 tensors are raw uint16 bit patterns; "f32" means IEEE float.
  */
@@ -341,6 +342,26 @@ int mh_pair_logits(const float* p, long ldp, const float* text, float* out, long
 int mh_zs_accumulate(const float* logits, float* mask_acc, float* map_acc, int B, int h, int S, float w, mh_stream_t s);
 int mh_rowmax_skip(const float* scores, long lds, float* acc, long rows, int cols, int period, float w, mh_stream_t s);
 int mh_bilinear_ac(const float* in, float* out, int B, int h, int w, int H, int W, int one_minus, mh_stream_t s);
+
+/* ---- opaque context: library state the caller owns explicitly ------------------------------------------------
+ * An mh_ctx holds (1) a split-K scratch record -- mh_ctx_set_workspace(ctx, NULL, ptr, bytes) the main scratch,
+ * (ctx, stream, ptr, bytes) that of one more stream that may split K concurrently; library calls use the record of the context
+ * made current by mh_ctx_make_current (NULL = the process default that mh_set_workspace fills) -- and (2) the gradient
+ * exchange of the data-parallel step (runner_base.py:94-98): an RCCL communicator, a side HIP stream and two events.
+ * mh_ctx_comm_id writes the 128-byte id rank 0 generates; every rank passes it to mh_ctx_comm_init(ctx, id, rank, world).
+ * mh_allreduce_start(ctx, buf, n, producer): in-place sum of buf[0..n) f32 over the ranks on the context's side stream, ordered
+ * after what `producer` has queued; returns at once.  mh_allreduce_wait(ctx, consumer): `consumer` waits on the device for it.
+ * RCCL is dlopen'ed by the comm calls only (MH_ERR_UNSUPPORTED if it cannot be loaded); world == 1 needs no communicator. */
+typedef struct mh_ctx mh_ctx;
+int mh_ctx_create(mh_ctx** out);
+int mh_ctx_destroy(mh_ctx* ctx);
+int mh_ctx_set_workspace(mh_ctx* ctx, mh_stream_t stream, void* ptr, long bytes);
+int mh_ctx_make_current(mh_ctx* ctx);
+int mh_ctx_comm_id(void* id128);
+int mh_ctx_comm_init(mh_ctx* ctx, const void* id128, int rank, int world);
+int mh_ctx_world(const mh_ctx* ctx);
+int mh_allreduce_start(mh_ctx* ctx, float* buf, long n, mh_stream_t producer);
+int mh_allreduce_wait(mh_ctx* ctx, mh_stream_t consumer);
 
 /* library identity */
 const char* mh_version(void);

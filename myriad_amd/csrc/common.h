@@ -20,6 +20,17 @@ typedef __attribute__((ext_vector_type(16))) float float16_t;
     if (e__ != hipSuccess) return MH_ERR_LAUNCH;            \
   } while (0)
 
+// split-K scratch record (gemm.hip; one per mh_ctx + a process default)
+#define MH_MAX_ALT_WS 4
+struct MhScratch {
+  float* ws;
+  size_t bytes;
+  float* alt[MH_MAX_ALT_WS];
+  hipStream_t alt_stream[MH_MAX_ALT_WS];
+};
+extern MhScratch g_default_scratch;
+extern MhScratch* g_scratch;
+
 // launch profiler (prof.hip): no-ops unless mh_prof_start() was called
 extern bool g_mh_prof_on;
 void mh_prof_pre(hipStream_t s, int kernel, int M, int N, int K, int splits, int flags);

@@ -461,12 +461,15 @@ static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t str
   return MH_OK;
 }
 
-// caller-provided scratch for the automatic split-K path (no hidden allocation): mh_set_workspace once per device
-static float* g_ws = nullptr;
-static size_t g_ws_bytes = 0;
-#define MH_MAX_ALT_WS 4
-static float* g_ws_alt[MH_MAX_ALT_WS] = {nullptr, nullptr, nullptr, nullptr};
-static hipStream_t g_ws_alt_stream[MH_MAX_ALT_WS] = {nullptr, nullptr, nullptr, nullptr};
+// caller-provided scratch for the automatic split-K path (no hidden allocation).  It lives in a scratch record: the
+// process-default one (mh_set_workspace / mh_set_stream_workspace) or the record of the mh_ctx the caller made current
+// (ctx.hip: mh_ctx_make_current) -- SURVEY 8(b): library state behind an opaque context.
+MhScratch g_default_scratch = {nullptr, 0, {nullptr, nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr, nullptr}};
+MhScratch* g_scratch = &g_default_scratch;
+#define g_ws (g_scratch->ws)
+#define g_ws_bytes (g_scratch->bytes)
+#define g_ws_alt (g_scratch->alt)
+#define g_ws_alt_stream (g_scratch->alt_stream)
 extern "C" int mh_set_workspace(void* ptr, long bytes) {
   g_ws = (float*)ptr;
   g_ws_bytes = ptr ? (size_t)bytes : 0;

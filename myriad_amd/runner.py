@@ -64,6 +64,46 @@ def setup_seeds(seed: int, rank: int = 0) -> None:
     torch.manual_seed(s)
 
 
+class CtxCollective:
+    """The gradient all-reduce through the C ABI's context object (mh_ctx_*, mh_allreduce_start / _wait): RCCL communicator,
+    side stream and events live in the library; `start` orders the exchange behind the current stream and returns, `wait` makes
+    the current stream depend on it.  `dist` (any initialised process group) only carries the 128-byte communicator id."""
+
+    def __init__(self, device, rank: int, world: int, dist=None):
+        import ctypes
+        from . import _lib
+        self.lib, self.check = _lib.load(), _lib.check
+        self.dev = torch.device(device)
+        h = ctypes.c_void_p()
+        self.check(self.lib.mh_ctx_create(ctypes.addressof(h)), "mh_ctx_create")
+        self.h = h
+        idbuf = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            raw = (ctypes.c_ubyte * 128)()
+            self.check(self.lib.mh_ctx_comm_id(ctypes.addressof(raw)), "mh_ctx_comm_id")
+            idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+        if world > 1:
+            t = idbuf.to(self.dev) if dist.get_backend() == "nccl" else idbuf
+            dist.broadcast(t, src=0)
+            idbuf = t.cpu()
+        raw = (ctypes.c_ubyte * 128)(*idbuf.tolist())
+        with torch.cuda.device(self.dev):
+            self.check(self.lib.mh_ctx_comm_init(self.h, ctypes.addressof(raw), rank, world), "mh_ctx_comm_init")
+        self.world = world
+
+    def start(self, flat: torch.Tensor) -> None:
+        self.check(self.lib.mh_allreduce_start(self.h, flat.data_ptr(), flat.numel(), torch.cuda.current_stream().cuda_stream),
+                   "mh_allreduce_start")
+
+    def wait(self) -> None:
+        self.check(self.lib.mh_allreduce_wait(self.h, torch.cuda.current_stream().cuda_stream), "mh_allreduce_wait")
+
+    def close(self) -> None:
+        if self.h is not None:
+            self.lib.mh_ctx_destroy(self.h)
+            self.h = None
+
+
 class DataParallel:
     """Gradient exchange for one-process-per-GPU data parallelism over torch.distributed (backend 'nccl' is RCCL on ROCm;
     'gloo' in the CPU tests).  The unit of exchange is the model's flat buffer `store.flat_g_comm` = [gradients | per-module
@@ -96,6 +136,13 @@ class DataParallel:
             self.side = torch.cuda.Stream(device=device)
         self._pending = None
         self._bufs = {}
+        # MYRIAD_DP_COLLECTIVE=ctx: the all-reduce goes through the library's own verbs (mh_allreduce_start / _wait on an mh_ctx
+        # that owns an RCCL communicator and a side stream, include/myriad_hip.h) instead of torch.distributed; the process group
+        # is then only the channel that hands rank 0's communicator id to the other ranks.
+        self.ctx = None
+        if (os.environ.get("MYRIAD_DP_COLLECTIVE") == "ctx" and self.world > 1 and device is not None
+                and torch.device(device).type == "cuda" and self.mode == "allreduce" and self.grad_dtype == torch.float32):
+            self.ctx = CtxCollective(device, self.rank, self.world, dist)
         self._gloo = dist.is_initialized() and dist.get_backend() == "gloo"
 
     def _persistent(self, key: str, n: int, dtype, device) -> torch.Tensor:
@@ -161,6 +208,11 @@ class DataParallel:
             return
         n_grad = flat_g_comm.numel() if n_grad is None else n_grad
 
+        if self.ctx is not None:
+            self.ctx.start(flat_g_comm)
+            self._pending = True
+            return
+
         def go():
             if self.mode == "allreduce":
                 self._all_reduce(flat_g_comm)
@@ -175,6 +227,10 @@ class DataParallel:
         self._run(go)
 
     def wait(self) -> None:
+        if self._pending is not None and self.ctx is not None:
+            self.ctx.wait()
+            self._pending = None
+            return
         if self._pending is not None:
             if self.side is not None:
                 torch.cuda.current_stream().wait_stream(self.side)

@@ -730,3 +730,41 @@ def test_conv_layer_fwd_bwd_vs_torch():
     dcol = ops.gemm(dy, wpT)                       # [M, Kpad]
     dx = ops.col2im(dcol, B, H, W, Cin, 3, 3, 1)
     assert relerr(dx.permute(0, 3, 1, 2), xr.grad) < 2e-2
+
+
+def test_context_object_owns_scratch_and_the_gradient_exchange():
+    """the opaque mh_ctx.  (1) A split-K GEMM run while a context with its own scratch is current gives the bits of
+    the process-default scratch, and leaves that one untouched; (2) mh_allreduce_start / _wait on a one-rank RCCL communicator
+    created through the library (id -> init): the sum over one rank is the buffer itself, issued on the context's side stream
+    and handed back to the producer stream without a host synchronisation."""
+    import ctypes
+    from myriad_amd import _lib
+    from myriad_amd.runner import CtxCollective
+    lib = _lib.load()
+    ops.ensure_workspace(DEV)
+    a = bf(rnd(1184, 4096, seed=101)).to(DEV)
+    b = bf(rnd(4096, 4096, seed=102) * 0.05).to(DEV)
+    assert ops.gemm_plan(1184, 4096, 4096)[1] > 1
+    want = ops.gemm(a, b, out_dtype=torch.float32).clone()
+    cc = CtxCollective(DEV, 0, 1)
+    try:
+        own = torch.zeros(64 << 20, dtype=torch.uint8, device=DEV)
+        _lib.check(lib.mh_ctx_set_workspace(cc.h, None, own.data_ptr(), own.numel()), "mh_ctx_set_workspace")
+        _lib.check(lib.mh_ctx_make_current(cc.h), "mh_ctx_make_current")
+        got = ops.gemm(a, b, out_dtype=torch.float32)
+        torch.cuda.synchronize()
+        assert torch.equal(got, want) and int(own.view(torch.int32)[:1024].abs().sum()) != 0     # the context's scratch was used
+        _lib.check(lib.mh_ctx_make_current(None), "mh_ctx_make_current")
+        assert torch.equal(ops.gemm(a, b, out_dtype=torch.float32), want)
+        g = rnd(1 << 20, seed=103).to(DEV)
+        ref = g.clone()
+        g.mul_(2.0)                                                                              # producer work queued before the exchange
+        cc.start(g)
+        cc.wait()
+        g.add_(1.0)                                                                              # consumer work ordered behind it
+        torch.cuda.synchronize()
+        assert torch.equal(g, ref * 2.0 + 1.0)
+        assert lib.mh_ctx_world(cc.h) == 1
+    finally:
+        lib.mh_ctx_make_current(None)
+        cc.close()

@@ -164,3 +164,60 @@ def test_anomaly_detection_dataset_trains_with_the_reference_recipe(tmp_path):
     assert not torch.equal(sw["aug_image"], a["aug_image"])
     (root / "visa.jsonl").write_text("\n".join(json.dumps(r) for r in rows))
     assert AnomalyDetectionDataset(str(root), ["visa.jsonl"], seed=7).get_class_name(1)[0] == "visa"
+
+
+def test_resize_and_clone_edge_cases():
+    """Degenerate sizes the reference can reach: a 1-pixel-wide source (every destination column reads it), up- and down-
+    scaling by large factors, a clone mask that leaves fewer than 50 pixels (the patch is dropped, self_sup_tasks.py:277-278),
+    an ROI thinner than 3 pixels (nothing to solve: the destination is returned unchanged)."""
+    one = np.array([[[10, 20, 30]], [[200, 100, 50]]], np.uint8)                       # 2 x 1 source
+    up = O.resize_linear_u8(one, (5, 7))
+    assert up.shape == (7, 5, 3) and (up[:, 0] == up[:, 4]).all()                      # columns identical
+    assert up[0].tolist() == [[10, 20, 30]] * 5 and up[-1].tolist() == [[200, 100, 50]] * 5
+    assert np.array_equal(P.resize_linear_u8(one, (5, 7)), up)
+    r = np.random.RandomState(1)
+    big = r.randint(0, 256, (90, 70, 3)).astype(np.uint8)
+    for ds in ((7, 9), (210, 270), (1, 1), (70, 1)):
+        a, b = O.resize_linear_u8(big, ds), P.resize_linear_u8(big, ds)
+        assert a.shape == (ds[1], ds[0], 3) and np.array_equal(a, b)
+    dst = r.randint(0, 256, (64, 64, 3)).astype(np.uint8)
+    src = r.randint(0, 256, (12, 12, 3)).astype(np.uint8)
+    thin = np.zeros((12, 12), np.uint8)
+    thin[1:11, 5:7] = 255                                                               # ROI 10 x 2: no interior
+    assert np.array_equal(O.seamless_clone(src, dst, thin, (32, 32)), dst)
+    roi = P.clone_roi(thin, (32, 32), dst.shape[:2])
+    out = dst.copy()
+    P.poisson_clone_numpy(out, src, thin, roi)
+    assert np.array_equal(out, dst)
+    # a patch whose scaled mask keeps < 50 pixels is dropped by the plan (and by the reference): no operation, mask stays empty
+    np.random.seed(3)
+    ops, _ = P.plan(MK.test_image(11), MK.test_image(41), mode=1, num_patches=1, width_bounds_pct=((0.013, 0.02), (0.013, 0.02)),
+                    resize=False, shift=True, label_mode="binary")
+    assert ops == []
+    np.random.seed(3)
+    pe, lab, boxes = O.patch_ex(MK.test_image(11), MK.test_image(41), mode=1, num_patches=1, width_bounds_pct=((0.013, 0.02), (0.013, 0.02)),
+                                resize=False, shift=True, label_mode="binary")
+    assert np.array_equal(pe, MK.test_image(11)) and lab.sum() == 0 and boxes == []
+
+
+@pytest.mark.gpu
+def test_device_resize_kernel_matches_the_host_on_edge_sizes():
+    """mh_patch_resize_u8 (csrc/selfsup.hip) against the host restatement, bit for bit: up / down scaling, the exact 2 x 2
+    halving (area mean), identity, a 1-pixel-wide source box, boxes at the image border."""
+    from myriad_amd import _lib, ops as Ops
+    lib = _lib.load()
+    r = np.random.RandomState(9)
+    img = r.randint(0, 256, (2, 224, 224, 3)).astype(np.uint8)
+    dev_img = torch.from_numpy(img).cuda()
+    cases = [((0, 0, 40, 60), (60, 40)), ((10, 20, 40, 60), (30, 20)), ((100, 50, 37, 53), (80, 61)), ((0, 0, 224, 224), (112, 112)),
+             ((200, 180, 24, 44), (90, 11)), ((5, 7, 20, 1), (9, 33)), ((3, 3, 50, 50), (7, 90))]
+    for b, ((sy, sx, sh, sw), (w, h)) in enumerate(cases):
+        xi, xw = P.linear_resize_tables(sw, w)
+        yi, yw = P.linear_resize_tables(sh, h)
+        tabs = torch.from_numpy(np.concatenate([xi, xw.reshape(-1), yi, yw.reshape(-1)]).astype(np.int32)).cuda()
+        out = torch.empty((h, w, 3), dtype=torch.uint8, device="cuda")
+        tp = tabs.data_ptr()
+        _lib.check(lib.mh_patch_resize_u8(dev_img.data_ptr(), b % 2, 224, 224, sy, sx, sh, sw, tp, tp + 4 * w, tp + 4 * 3 * w,
+                                          tp + 4 * (3 * w + h), out.data_ptr(), h, w, Ops._s()), "mh_patch_resize_u8")
+        want = P.resize_linear_u8(img[b % 2, sy:sy + sh, sx:sx + sw], (w, h))
+        assert np.array_equal(out.cpu().numpy(), want), (sy, sx, sh, sw, w, h)

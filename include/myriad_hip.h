@@ -264,7 +264,7 @@ int mh_gemv_packed_silu(const void* gu, long ldgu, const void* P, void* C, int l
  * phase's weights, so the HBM stream does not drain at phase boundaries the way it does at launch boundaries.  Bit-identical
  * to the separate launches.  layers: device array of n_layers records of 7 pointers {wqkv, wo, wgu, wd (mh_gemv_pack copies),
  * ln1, ln2 (f32), cache [B][T_cap][2D] bf16}; h: the embedded token on entry, the residual stream after (h2 its twin);
- * qkv / o / gu: scratch [M, 3D] / [M, D] / [M, 2I] bf16; bar: two zeroed uint32 owned by the caller ([1] is raised if a
+ * qkv / o / gu: scratch [M, 3D] / [M, D] / [M, 2I] bf16; bar: 1024 zeroed uint32 owned by the caller ([1] is raised if a
  * barrier ever times out: the step is then invalid); n_wg: workgroups = CUs certainly free (all must be resident).
  * MH_ERR_UNSUPPORTED outside M <= 2, head_dim 128, D <= 4096 (multiple of 1024), I % 128 == 0, LLaMA-7B-like block counts. */
 long mh_decode_mega_lds_bytes(int M, int D, int I, int T_cap);

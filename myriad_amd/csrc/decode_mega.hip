@@ -55,42 +55,64 @@ struct MegaParams {
   const float* sn;
   long cache_bs;
   int ld_cache;
-  unsigned* bar;               // [0] arrival counter (zeroed by mg_reset_kernel in front of every launch), [1] abort flag (sticky)
+  unsigned* bar;               // MG_BAR_WORDS uint32: barrier counters (mg_arrive), [1] = sticky abort flag
   long long* trace;            // debug: workgroup 0 stamps the 100 MHz counter at every phase boundary of layer 1 (NULL: off)
 };
 #define MG_STAMP(i) if (p.trace && li == 1 && blockIdx.x == 0 && threadIdx.x == 0) p.trace[i] = (long long)__builtin_amdgcn_s_memrealtime();
 
 struct MgBatch { short8_t w0[MG_U], w1[MG_U]; };
 
-// ---- grid barrier in two halves: arrive (lane 0 publishes this workgroup's stores and counts itself in), then the caller
-// requests the next phase's weights, then wait (relaxed polling, one acquire).  The release drains the wave's vector-memory
-// counter, so the weight requests must come AFTER it -- otherwise arriving would wait for them. ------------------------------
-__device__ __forceinline__ void mg_arrive(unsigned* bar, unsigned& target, int nwg) {
-  // every cross-workgroup output of a phase is written with agent-scope (write-through, `sc1`) stores, so publishing it needs
-  // no L2 write-back fence (6-17 us per barrier measured with one): each wave drains its own stores, then lane 0 counts in
+// ---- grid barrier, XCD-hierarchical, in two halves ---------------------------------------------------------------------
+// Workgroups are grouped by blockIdx & 7 (the dispatcher deals workgroups round-robin over the 8 XCDs, so a group shares an
+// L2).  arrive: every wave drains its stores (all cross-workgroup outputs are agent-scope write-through stores: no L2
+// write-back fence is needed), lane 0 counts into ITS group's counter.  The last arriver of a group counts into the top
+// counter, polls it until all groups are in, then publishes the group's generation; everybody else polls that generation word
+// -- a line in its own XCD's L2, so 248 of the 256 pollers never touch the fabric.  One acquire (L1 invalidate) per workgroup.
+// Layout of `bar` (uint32, zeroed by mg_reset_kernel before the launch): [0] top counter, [1] abort flag (sticky across
+// launches: never zeroed), [32 (1 + x)] counter of group x, [32 (9 + x)] generation of group x.
+#define MG_BAR_WORDS (32 * 17)
+struct MgBar { unsigned gen; int leader; };
+__device__ __forceinline__ void mg_arrive(unsigned* bar, MgBar& st, int nwg) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  target += (unsigned)nwg;
-}
-__device__ __forceinline__ void mg_store_f32(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void mg_store_u16(bf16_t* p, bf16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void mg_store_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ void mg_wait(unsigned* bar, unsigned target) {
+  st.gen += 1;
+  st.leader = 0;
   if (threadIdx.x == 0) {
+    const int x = blockIdx.x & 7;
+    const unsigned members = (unsigned)((nwg - x + 7) / 8);             // workgroups with blockIdx & 7 == x
+    const unsigned old = __hip_atomic_fetch_add(bar + 32 * (1 + x), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (old + 1 == st.gen * members) {                                  // last of the group
+      st.leader = 1;
+      __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+__device__ __forceinline__ void mg_wait(unsigned* bar, const MgBar& st, int nwg) {
+  if (threadIdx.x == 0) {
+    const int x = blockIdx.x & 7;
+    const unsigned groups = nwg < 8 ? (unsigned)nwg : 8u;
     unsigned spins = 0;
-    while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-      __builtin_amdgcn_s_sleep(2);
-      if (++spins > (1u << 23)) {                           // ~seconds: a workgroup never arrived -- give up instead of hanging
-        __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
+    if (st.leader) {
+      while ((int)(__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - st.gen * groups) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 23)) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if ((spins & 1023u) == 0 && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
       }
-      if ((spins & 1023u) == 0 && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      __hip_atomic_store(bar + 32 * (9 + x), st.gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      while ((int)(__hip_atomic_load(bar + 32 * (9 + x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - st.gen) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if (++spins > (1u << 23)) { __hip_atomic_store(bar + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+        if ((spins & 1023u) == 0 && __hip_atomic_load(bar + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) break;
+      }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
   }
   __syncthreads();
 }
+__device__ __forceinline__ void mg_store_f32(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mg_store_u16(bf16_t* p, bf16_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void mg_store_u32(unsigned* p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
 // ---- GEMV over the packed copy: NWP = waves per 16-column block in the layout (4: two blocks per workgroup pass, 8: one) ----
 template <int NWP>
@@ -385,7 +407,7 @@ __global__ __launch_bounds__(MG_NT, 2) void decode_mega_kernel(MegaParams p) {
   __shared__ float bred[MG_NW];
   const int g = blockIdx.x, G = gridDim.x;
   const int M = p.M, D = p.D, I = p.I;
-  unsigned target = 0;                                     // mg_reset_kernel zeroed the counter in front of this launch
+  MgBar target = {0u, 0};                                  // mg_reset_kernel zeroed the counters in front of this launch
   MgBatch b;
   float* h = p.h;
   float* h2 = p.h2;
@@ -400,13 +422,13 @@ __global__ __launch_bounds__(MG_NT, 2) void decode_mega_kernel(MegaParams p) {
     MG_STAMP(2)
     mg_arrive(p.bar, target, G);
     mg_prefetch<8>(L.wo, D, D, g, b);                      // all of o_proj: 16 KiB per wave
-    mg_wait(p.bar, target);
+    mg_wait(p.bar, target, G);
     MG_STAMP(3)
     // P2: rotary + append + attention, one (row, head) per workgroup
     for (int unit = g; unit < M * p.H; unit += G) mg_attention(p, L, unit, sc, part);
     MG_STAMP(4)
     mg_arrive(p.bar, target, G);
-    mg_wait(p.bar, target);
+    mg_wait(p.bar, target, G);
     MG_STAMP(5)
     // P3: o_proj + residual
     mg_rows_copy(p.o, M, D, xs);
@@ -414,7 +436,7 @@ __global__ __launch_bounds__(MG_NT, 2) void decode_mega_kernel(MegaParams p) {
     MG_STAMP(6)
     mg_arrive(p.bar, target, G);
     mg_prefetch<4>(L.wgu, 2 * I, D, g, b);
-    mg_wait(p.bar, target);
+    mg_wait(p.bar, target, G);
     MG_STAMP(7)
     // P4: gate | up
     mg_rows_rmsnorm(h2, L.ln2, M, D, p.eps, xs, bred);
@@ -423,7 +445,7 @@ __global__ __launch_bounds__(MG_NT, 2) void decode_mega_kernel(MegaParams p) {
     MG_STAMP(9)
     mg_arrive(p.bar, target, G);
     mg_prefetch<8>(L.wd, D, I, g, b);
-    mg_wait(p.bar, target);
+    mg_wait(p.bar, target, G);
     MG_STAMP(10)
     // P5: SiLU gate + down projection + residual
     mg_rows_silu(p.gu, M, I, xs);
@@ -433,14 +455,17 @@ __global__ __launch_bounds__(MG_NT, 2) void decode_mega_kernel(MegaParams p) {
     mg_arrive(p.bar, target, G);
     if (li + 1 < p.n_layers) mg_prefetch<4>(p.layers[li + 1].wqkv, 3 * D, D, g, b);
     else mg_prefetch<4>(p.lm_head, p.V, D, g, b);
-    mg_wait(p.bar, target);
+    mg_wait(p.bar, target, G);
     MG_STAMP(13)
   }
   mg_rows_rmsnorm(h, p.norm, M, D, p.eps, xs, bred);
   mg_gemv<4>(p.lm_head, p.V, D, xs, M, red, p.logits, p.V, 1, nullptr, 0, g, G, b);
 }
 
-__global__ void mg_reset_kernel(unsigned* bar) { bar[0] = 0u; }
+__global__ void mg_reset_kernel(unsigned* bar) {
+  for (int i = threadIdx.x; i < MG_BAR_WORDS; i += blockDim.x)
+    if (i != 1) bar[i] = 0u;
+}
 
 static long long* g_mega_trace = nullptr;
 extern "C" void mhdbg_set_mega_trace(void* ptr) { g_mega_trace = (long long*)ptr; }   // debug hook, not part of the ABI
@@ -451,7 +476,7 @@ extern "C" long mh_decode_mega_lds_bytes(int M, int D, int I, int T_cap) {
 }
 
 // layers: device array of n_layers MegaLayer records (7 pointers each: packed wqkv [3D, D], wo [D, D], wgu [2I, D] 128-blocked
-// gate|up, wd [D, I]; ln1, ln2 f32 [D]; cache [B][T_cap][2D] bf16).  bar: 2 zero-initialised unsigneds owned by the caller:
+// gate|up, wd [D, I]; ln1, ln2 f32 [D]; cache [B][T_cap][2D] bf16).  bar: 1024 zero-initialised unsigneds owned by the caller (MG_BAR_WORDS used):
 // [0] the barrier's arrival counter (a one-thread launch in front of the kernel zeroes it), [1] a sticky abort flag a
 // workgroup raises if a barrier ever times out (the step's results are then garbage: check it).  n_wg: workgroups = CUs that
 // are certainly free (all must be resident at once).  Returns MH_ERR_UNSUPPORTED for shapes the kernel does not cover (M > 2,
@@ -478,7 +503,7 @@ extern "C" int mh_decode_mega(const void* layers, int n_layers, int M, int D, in
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)decode_mega_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }
   if (sh > 96 * 1024) return MH_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(mg_reset_kernel, dim3(1), dim3(1), 0, stream, (unsigned*)bar);
+  hipLaunchKernelGGL(mg_reset_kernel, dim3(1), dim3(256), 0, stream, (unsigned*)bar);
   hipLaunchKernelGGL(decode_mega_kernel, dim3(n_wg), dim3(MG_NT), sh, stream, p);
   MH_CHECK_LAUNCH();
   return MH_OK;

@@ -336,7 +336,7 @@ class LlamaHIP:
                                   qkv=torch.empty((B, 3 * self.D), dtype=BF16, device=dev),
                                   o=torch.empty((B, self.D), dtype=BF16, device=dev),
                                   gu=torch.empty((B, 2 * I), dtype=BF16, device=dev),
-                                  bar=torch.zeros((4,), dtype=torch.int32, device=dev),
+                                  bar=torch.zeros((1024,), dtype=torch.int32, device=dev),
                                   n_wg=torch.cuda.get_device_properties(dev).multi_processor_count)
             self._decode_ws[key] = ws
         return ws

@@ -18,7 +18,8 @@
 // Same arithmetic as the separate kernels: the GEMV walks the packed weight copy exactly as gemv_kernel<2> (same k per
 // lane, waves reduced through LDS in wave order), the norm / gate expressions are those of rmsnorm_fwd_kernel /
 // silu_mul_fwd_kernel, the attention is attn_decode_kernel's with its 16 waves emulated by 8 (each runs two of the
-// original waves' key sets and partial outputs, reduced in the original order) -- logits are bit-identical.
+// original waves' key sets and partial outputs, reduced in the original order) -- logits are bit-identical.  (The rotated q is
+// kept in LDS, so the q columns of the `qkv` scratch stay un-rotated here; nothing else reads them.)
 #include "common.h"
 
 #define MG_NW 8
@@ -268,6 +269,7 @@ __device__ __forceinline__ void mg_rows_copy(const bf16_t* x, int M, int K, bf16
 
 // attn_decode_kernel for one (b, head) with its rotary + KV append prologue, 16 waves emulated by 8 (vw = wave, wave + 8)
 __device__ __forceinline__ void mg_attention(const MegaParams& p, const MegaLayer& L, int unit, float* sc, float* part) {
+  __shared__ __attribute__((aligned(16))) bf16_t qs[128];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int D = p.hd, H = p.H, W = p.H * p.hd;
   const int b = unit / H, h = unit % H;
@@ -293,7 +295,10 @@ __device__ __forceinline__ void mg_attention(const MegaParams& p, const MegaLaye
         oa[t] = (short)f2bf(x1 * c4[t] - x2 * s4[t]);
         ob[t] = (short)f2bf(x2 * c4[t] + x1 * s4[t]);
       }
-      bf16_t* dst = which == 0 ? e : crow + h * D + i;
+      // the rotated q stays in LDS.  (In place in `qkv`, as the per-op kernel does, a plain store would leave a dirty line in
+      // this XCD's L2 that the NEXT layer's write-through store of the same element -- from a workgroup on another XCD -- does
+      // not see: the stale line then wins or loses by eviction order.  Found as a 1-in-600-tokens mismatch.)
+      bf16_t* dst = which == 0 ? qs + i : crow + h * D + i;
       *reinterpret_cast<short4_t*>(dst) = oa;
       *reinterpret_cast<short4_t*>(dst + half) = ob;
     } else if (tid < 2 * items + (D >> 3)) {
@@ -302,7 +307,7 @@ __device__ __forceinline__ void mg_attention(const MegaParams& p, const MegaLaye
     }
     __syncthreads();
   }
-  const bf16_t* qp = src + h * D;
+  const bf16_t* qp = qs;
   const bf16_t* kp = cache_b + h * D;
   const bf16_t* vp = cache_b + W + h * D;
   const int ldk = p.ld_cache;

@@ -21,6 +21,7 @@
 // original waves' key sets and partial outputs, reduced in the original order) -- logits are bit-identical.  (The rotated q is
 // kept in LDS, so the q columns of the `qkv` scratch stay un-rotated here; nothing else reads them.)
 #include "common.h"
+#include <cstdlib>
 
 #define MG_NW 8
 #define MG_NT (MG_NW * 64)
@@ -57,6 +58,7 @@ struct MegaParams {
   long cache_bs;
   int ld_cache;
   unsigned* bar;               // MG_BAR_WORDS uint32: barrier counters (mg_arrive), [1] = sticky abort flag
+  int dbg;                     // debug (MYRIAD_MEGA_DBG): 1 = barriers do not wait, 2 = no attention phase -- WRONG RESULTS, timing only
   long long* trace;            // debug: workgroup 0 stamps the 100 MHz counter at every phase boundary of layer 1 (NULL: off)
 };
 #define MG_STAMP(i) if (p.trace && li == 1 && blockIdx.x == 0 && threadIdx.x == 0) p.trace[i] = (long long)__builtin_amdgcn_s_memrealtime();
@@ -73,9 +75,10 @@ struct MgBatch { short8_t w0[MG_U], w1[MG_U]; };
 // launches: never zeroed), [32 (1 + x)] counter of group x, [32 (9 + x)] generation of group x.
 #define MG_BAR_WORDS (32 * 17)
 struct MgBar { unsigned gen; int leader; };
-__device__ __forceinline__ void mg_arrive(unsigned* bar, MgBar& st, int nwg) {
+__device__ __forceinline__ void mg_arrive(unsigned* bar, MgBar& st, int nwg, int dbg = 0) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  if (dbg & 1) return;
   st.gen += 1;
   st.leader = 0;
   if (threadIdx.x == 0) {
@@ -88,8 +91,8 @@ __device__ __forceinline__ void mg_arrive(unsigned* bar, MgBar& st, int nwg) {
     }
   }
 }
-__device__ __forceinline__ void mg_wait(unsigned* bar, const MgBar& st, int nwg) {
-  if (threadIdx.x == 0) {
+__device__ __forceinline__ void mg_wait(unsigned* bar, const MgBar& st, int nwg, int dbg = 0) {
+  if (threadIdx.x == 0 && !(dbg & 1)) {
     const int x = blockIdx.x & 7;
     const unsigned groups = nwg < 8 ? (unsigned)nwg : 8u;
     unsigned spins = 0;
@@ -425,42 +428,43 @@ __global__ __launch_bounds__(MG_NT, 2) void decode_mega_kernel(MegaParams p) {
     MG_STAMP(1)
     mg_gemv<4>(L.wqkv, 3 * D, D, xs, M, red, p.qkv, 3 * D, 0, nullptr, 0, g, G, b);
     MG_STAMP(2)
-    mg_arrive(p.bar, target, G);
+    mg_arrive(p.bar, target, G, p.dbg);
     mg_prefetch<8>(L.wo, D, D, g, b);                      // all of o_proj: 16 KiB per wave
-    mg_wait(p.bar, target, G);
+    mg_wait(p.bar, target, G, p.dbg);
     MG_STAMP(3)
     // P2: rotary + append + attention, one (row, head) per workgroup
-    for (int unit = g; unit < M * p.H; unit += G) mg_attention(p, L, unit, sc, part);
+    if (!(p.dbg & 2))
+      for (int unit = g; unit < M * p.H; unit += G) mg_attention(p, L, unit, sc, part);
     MG_STAMP(4)
-    mg_arrive(p.bar, target, G);
-    mg_wait(p.bar, target, G);
+    mg_arrive(p.bar, target, G, p.dbg);
+    mg_wait(p.bar, target, G, p.dbg);
     MG_STAMP(5)
     // P3: o_proj + residual
     mg_rows_copy(p.o, M, D, xs);
     mg_gemv<8>(L.wo, D, D, xs, M, red, h2, D, 1, h, D, g, G, b);
     MG_STAMP(6)
-    mg_arrive(p.bar, target, G);
+    mg_arrive(p.bar, target, G, p.dbg);
     mg_prefetch<4>(L.wgu, 2 * I, D, g, b);
-    mg_wait(p.bar, target, G);
+    mg_wait(p.bar, target, G, p.dbg);
     MG_STAMP(7)
     // P4: gate | up
     mg_rows_rmsnorm(h2, L.ln2, M, D, p.eps, xs, bred);
     MG_STAMP(8)
     mg_gemv<4>(L.wgu, 2 * I, D, xs, M, red, p.gu, 2 * I, 0, nullptr, 0, g, G, b);
     MG_STAMP(9)
-    mg_arrive(p.bar, target, G);
+    mg_arrive(p.bar, target, G, p.dbg);
     mg_prefetch<8>(L.wd, D, I, g, b);
-    mg_wait(p.bar, target, G);
+    mg_wait(p.bar, target, G, p.dbg);
     MG_STAMP(10)
     // P5: SiLU gate + down projection + residual
     mg_rows_silu(p.gu, M, I, xs);
     MG_STAMP(11)
     mg_gemv<8>(L.wd, D, I, xs, M, red, h, D, 1, h2, D, g, G, b);
     MG_STAMP(12)
-    mg_arrive(p.bar, target, G);
+    mg_arrive(p.bar, target, G, p.dbg);
     if (li + 1 < p.n_layers) mg_prefetch<4>(p.layers[li + 1].wqkv, 3 * D, D, g, b);
     else mg_prefetch<4>(p.lm_head, p.V, D, g, b);
-    mg_wait(p.bar, target, G);
+    mg_wait(p.bar, target, G, p.dbg);
     MG_STAMP(13)
   }
   mg_rows_rmsnorm(h, p.norm, M, D, p.eps, xs, bred);
@@ -504,6 +508,8 @@ extern "C" int mh_decode_mega(const void* layers, int n_layers, int M, int D, in
   p.eps = eps; p.scale = scale; p.h = h; p.h2 = h2; p.qkv = (bf16_t*)qkv; p.o = (bf16_t*)o; p.gu = (bf16_t*)gu; p.norm = norm;
   p.lm_head = (const bf16_t*)lm_head; p.logits = logits; p.pos = pos; p.pos_dev = pos_dev; p.kvlen = kvlen; p.cs = cos_tab; p.sn = sin_tab;
   p.cache_bs = cache_bstride; p.ld_cache = (int)ld_cache; p.bar = (unsigned*)bar; p.trace = g_mega_trace;
+  static const int dbg = getenv("MYRIAD_MEGA_DBG") ? atoi(getenv("MYRIAD_MEGA_DBG")) : 0;
+  p.dbg = dbg;
   const size_t sh = (size_t)mh_decode_mega_lds_bytes(M, D, I, T_cap);
   static bool attr = false;
   if (!attr) { (void)hipFuncSetAttribute((const void*)decode_mega_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024); attr = true; }

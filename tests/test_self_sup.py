@@ -129,6 +129,33 @@ def test_poisson_clone_properties():
     assert np.array_equal(out2, out)
 
 
+def test_restated_opencv_algorithms_agree_with_independent_implementations():
+    """Not a pin (OpenCV itself is absent), but two independent implementations of the same published mathematics:
+    (1) bilinear resampling on half-pixel centres with clamped borders, in floating point (torch, align_corners=False, no
+    antialiasing -- INTER_LINEAR's geometry): the 11-bit fixed-point restatement may differ by one grey level, never two;
+    (2) the Dirichlet Poisson problem solved by a sparse direct solver (scipy) instead of the sine transform."""
+    import torch
+    import torch.nn.functional as F
+    r = np.random.RandomState(11)
+    img = r.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    for ds in ((80, 50), (33, 29), (53, 60), (20, 41), (106, 74), (7, 5)):
+        t = torch.from_numpy(img).permute(2, 0, 1)[None].double()
+        ref = F.interpolate(t, size=(ds[1], ds[0]), mode="bilinear", align_corners=False, antialias=False)[0].permute(1, 2, 0).numpy()
+        got = O.resize_linear_u8(img, ds).astype(np.float64)
+        assert np.abs(got - ref).max() <= 1.0 + 1e-9, ds             # rounding of the 11-bit weights + the final round
+        assert np.abs(got - ref).mean() < 0.35, ds
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spl
+    for (h, w) in ((9, 12), (23, 17), (40, 31)):
+        nh, nw = h - 2, w - 2
+        rhs = r.randn(nh, nw) * 30
+        lap1 = lambda n: sp.diags([np.ones(n - 1), -2 * np.ones(n), np.ones(n - 1)], [-1, 0, 1])
+        A = sp.kron(lap1(nh), sp.identity(nw)) + sp.kron(sp.identity(nh), lap1(nw))
+        want = spl.spsolve(A.tocsc(), rhs.ravel()).reshape(nh, nw)
+        got = O.poisson_dirichlet(rhs, h, w)
+        assert np.abs(got - want).max() < 1e-9 * max(1.0, np.abs(want).max())
+
+
 def test_dataset_arguments_follow_the_reference_tables():
     """anomaly_detection.py:50-65,118-141,254-264: per-class width bounds / logistic parameters / background for MVTec, the
     VisA set otherwise; both resample the patch and blend with NORMAL_CLONE."""

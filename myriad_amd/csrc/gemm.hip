@@ -49,6 +49,17 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("" ::: "memory");
 }
 
+// tile t may be read once at most `behind` younger tiles' loads (LPT LDS-DMA instructions each) are still in flight
+template <int LPT, int MAXB>
+__device__ __forceinline__ void wait_behind(int behind) {
+  if constexpr (MAXB <= 0) {
+    wait_vmcnt<0>();
+  } else {
+    if (behind >= MAXB) wait_vmcnt<MAXB * LPT>();
+    else wait_behind<LPT, MAXB - 1>(behind);
+  }
+}
+
 // STAGING: 0 = LDS-DMA ring (NST stages), 1 = register-staged double buffer (NST must be 2; A/B-test reference)
 template <int STAGING, int NST, int TBN, int MINB, int TBK, int NW, int TBM>
 __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void gemm_nt_kernel(const bf16_t* __restrict__ A,
@@ -154,11 +165,7 @@ __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void gemm_nt_kernel(const b
       // loads issued after tile t's own: LPT * (tiles in flight behind it)
       const int issued = (t + NST - 1) < nt ? (t + NST - 1) : nt;
       const int behind = issued - (t + 1);
-      if (NST >= 6 && behind >= 4) wait_vmcnt<4 * LPT>();
-      else if (NST >= 5 && behind >= 3) wait_vmcnt<3 * LPT>();
-      else if (NST >= 4 && behind >= 2) wait_vmcnt<2 * LPT>();
-      else if (NST >= 3 && behind >= 1) wait_vmcnt<LPT>();
-      else wait_vmcnt<0>();
+      wait_behind<LPT, NST - 2>(behind);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();   // tile t visible to all waves; everyone is done reading stage (t-1)%NST
       if (t + NST - 1 < nt) {
@@ -292,6 +299,7 @@ static int dispatch(const GemmArgs& g, hipStream_t stream) {
     case 8: return launch_gemm<0, 4, 128, 2, 32>(g, stream);   // BK=32: 64 KiB, 2 blocks/CU, 3 tiles in flight
     case 9: return launch_gemm<0, 2, 128, 2, 64, 8>(g, stream);   // 8 waves/block (wave tile 32x64), 2 blocks/CU
     case 10: return launch_gemm<0, 4, 128, 1, 64, 8>(g, stream);  // 8 waves/block, 4-deep ring, 1 block/CU
+    case 11: return launch_gemm<0, 8, 64, 1, 64, 4, 64>(g, stream);     // 64x64 tile, 8-deep ring (128 KiB): 7 K tiles in flight, 1 block/CU
     case 13: return launch_gemm<0, 6, 64, 1>(g, stream);          // 128x64, 6-deep ring (144 KiB): 5 K tiles in flight, 1 block/CU
     case 14: return launch_gemm<0, 4, 128, 1, 64, 4, 160>(g, stream);   // 160x128 tile, 4-deep ring (144 KiB): the M <= 160 rows of the
     case 15: return launch_gemm<0, 4, 96, 1, 64, 4, 160>(g, stream);    // batch-1 step as ONE row tile, 160x96 (128 KiB) when N / 96 fills the chip

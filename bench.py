@@ -65,7 +65,7 @@ def make_samples(B: int, vocab: int, seed: int, device):
 
 
 KERNEL_NAMES = {1: "gemm_nt_kernel<128x128>", 2: "gemm_256_kernel", 3: "gemm_nt_kernel<128x64>", 4: "gemm_nt_kernel<160x128>",
-                5: "gemm_nt_kernel<160x96>"}
+                5: "gemm_nt_kernel<160x96>", 6: "gemm_nt_kernel<64x64>"}
 GEMM_OUT_F32 = 1
 
 

@@ -270,7 +270,7 @@ static int launch_gemm(const GemmArgs& g, hipStream_t stream) {
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
     attr_set = true;
   }
-  if (g_mh_prof_on) mh_prof_pre(stream, TBM == 160 ? (TBN == 96 ? 5 : 4) : (TBN == 64 ? 3 : 1), g.M, g.N, g.K, g.splits, g.flags);
+  if (g_mh_prof_on) mh_prof_pre(stream, TBM == 160 ? (TBN == 96 ? 5 : 4) : (TBM == 64 ? 6 : (TBN == 64 ? 3 : 1)), g.M, g.N, g.K, g.splits, g.flags);
   // tps / kt_per_split are in units of 64-deep K tiles at the call sites; rescale for 32-deep kernels
   hipLaunchKernelGGL((gemm_nt_kernel<STAGING, NST, TBN, MINB, TBK, NW, TBM>), grid, block, shmem, stream, (const bf16_t*)g.A,
                      (const bf16_t*)g.B, g.C, g.bias, g.residual, g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.ldr, g.flags,
@@ -550,7 +550,9 @@ static int big_tile_splits(int M, int N, int K, int tile_n) {
 }
 
 // plan kernel id -> forced-variant number of dispatch()
-static inline int plan_variant(int kernel) { return kernel == 2 ? 12 : (kernel == 3 ? 3 : (kernel == 4 ? 14 : (kernel == 5 ? 15 : 0))); }
+static inline int plan_variant(int kernel) {
+  return kernel == 2 ? 12 : (kernel == 3 ? 3 : (kernel == 4 ? 14 : (kernel == 5 ? 15 : (kernel == 6 ? 11 : 0))));
+}
 
 // The automatic policy (flags carry no variant): which kernel runs and with how many K splits.
 //   kernel 0: gemv.hip weight streaming (M <= 16: decode)
@@ -559,6 +561,7 @@ static inline int plan_variant(int kernel) { return kernel == 2 ? 12 : (kernel =
 //             profiles/r01_gemm_256.md)
 //   kernel 1: the 128x128 kernel for everything smaller -- it co-schedules two workgroups per CU and so hides its
 //             own prologue / store tail, which the one-workgroup-per-CU 256x256 kernel cannot
+//   kernel 6: 64x64 tiles, 8-deep ring, for one-round grids with short K (see gemm_plan)
 //   kernel 3: the same kernel with a 128x64 tile and a 3-deep ring when even the 128x128 grid leaves most CUs without a
 //             workgroup (Q-Former / VE-net shapes: 648x768 is 36 tiles).  A lone workgroup streams its operands at one
 //             CU's L2 rate (~0.5 us per 64-deep step), so twice the workgroups is twice the CUs pulling: 14 -> 10 us at
@@ -618,6 +621,15 @@ static void gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits) 
   if (can_split) {
     const int s = auto_splits(M, N, K);
     if (s > 1 && (size_t)s * M * N * sizeof(float) <= g_ws_bytes) *splits = s;
+  }
+  // kernel 6: one round of 64x64 tiles with an 8-deep ring (7 k-tiles in flight, 128 KiB of LDS, one workgroup per CU) when
+  // that round fits the chip and K is short: a K = 768 product has all 12 of its k-tiles requested before the first MFMA, so
+  // the launch is one memory latency instead of four (round 3, tools/gemm_small_sweep.py, back-to-back launches: 648x768x768
+  // 9.9 -> 8.2 us, 81x768x768 split 3 + reduce 10.3 -> 8.1, 648x768x2304 19.2 -> 14.8, 81x3072x768 11.0 -> 8.4,
+  // 256x1408x640 11.4 -> 8.0); never K-split, so no scratch and no reduce launch behind it
+  {
+    const long t64 = (long)((M + 63) / 64) * ((N + 63) / 64);
+    if (M > 16 && t64 <= 256 && K <= 3072 && K >= 256) { *kernel = 6; *splits = 1; return; }
   }
   const long t128 = (long)((M + BM - 1) / BM) * ((N + 127) / 128);
   // < 256: the 128x128 grid would not give every CU a workgroup (round 3, tools/gemm_small_sweep.py: 2056x1408x1408, 187

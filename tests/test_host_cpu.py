@@ -326,7 +326,9 @@ def test_gemm_policy_for_the_steps_shapes():
         assert plan(2056, 6144, 1408) == (2, 1)                                          # ViT fc1
         assert plan(2056, 1408, 1408) == (3, 1)                                          # ViT proj: 187 tiles of 128^2 < 256 CUs -> 128x64 tiles
         assert plan(4096, 25600, 128)[0] == 1                                            # K = 128 (VETokenizer head wgrad): 128x128 kernel
-        assert plan(256, 768, 768)[0] == 3 and plan(648, 768, 2304)[0] == 3              # Q-Former sizes: 128x64 tiles fill more CUs
+        assert plan(648, 2304, 768)[0] == 3 and plan(648, 3072, 768)[0] == 3             # Q-Former sizes: 128x64 tiles fill more CUs
+        assert plan(256, 768, 768) == (6, 1) and plan(648, 768, 2304) == (6, 1)          # one round of 64x64 tiles, short K: deep ring, never split
+        assert plan(81, 768, 768) == (6, 1) and plan(81, 768, 4096)[0] != 6              # ... only up to K = 3072
         assert plan(72, 4096, 25664)[0] == 1                                             # conv-stem head: 16 K splits fill the chip
         # batch-1 step: 148 LLaMA rows / 257 ViT rows as one / two 160-row tiles, the weight streamed once, one round of workgroups
         assert plan(148, 22016, 4096) == (5, 1) and plan(148, 12288, 4160) == (5, 2) and plan(148, 4096, 22016) == (4, 8)

@@ -9,7 +9,8 @@ L = _lib.load()
 dev = torch.device("cuda:0")
 ops.ensure_workspace(dev)
 SHAPES = [(2056, 1408, 1408), (81, 768, 768), (81, 3072, 768), (648, 768, 768), (648, 768, 2304), (648, 2304, 768), (648, 3072, 768), (648, 768, 3072), (2056, 1536, 1408),
-          (2056, 1408, 1536), (256, 768, 768), (256, 1408, 640), (648, 4096, 768), (392, 768, 1024)]
+          (2056, 1408, 1536), (256, 768, 768), (256, 1408, 640), (648, 4096, 768), (392, 768, 1024),
+          (257, 1408, 1408), (196, 2368, 1024), (784, 640, 256), (81, 768, 3072), (81, 768, 2304), (81, 2304, 768)]
 VAR_SHIFT = None
 
 

@@ -20,6 +20,7 @@
 // shuffles) and P is already the B operand of O^T = V^T.P^T.  The V^T A-operand (row d = lane & 15, reduction elements
 // = keys {32c + 4g + r} U {32c + 16 + 4g + r}) is two transpose reads of [4 keys][16 d] blocks of the key-major image.
 #include "common.h"
+#include <cstdlib>
 
 #define AS_D 128
 #define AS_RS 144            // LDS row stride in elements
@@ -44,7 +45,9 @@ struct AttnSeqParams {
   const bf16_t* dout_bf; // or bf16 [B*S, ldd]
   int nslab; long slab; int ldd;
   bf16_t* dqkv;          // [B, S, ld]  dq | dk | dv (dq, dk un-rotated)
+  long long* trace;      // debug: workgroup 0's waves 0 and 7 stamp the 100 MHz counter at the phase boundaries (NULL: off)
 };
+#define AS_STAMP(i) if (p.trace && blockIdx.x == 0 && blockIdx.y == 0 && (threadIdx.x == 0 || threadIdx.x == 448)) p.trace[(threadIdx.x ? 16 : 0) + (i)] = (long long)__builtin_amdgcn_s_memrealtime();
 
 // rotate-half rotary on one 8-element chunk pair (columns c .. c+7 and c+64 .. c+71), fp32, one rounding
 __device__ __forceinline__ void as_rope_pair(short8_t& a, short8_t& b, const float* cs, const float* sn, float sign) {
@@ -277,35 +280,68 @@ __global__ __launch_bounds__(AS_NW * 64) void attn_seq_fwd_kernel(AttnSeqParams 
 // the same bits as the separate reduce launch this replaces) or as a plain bf16 matrix.
 __device__ __forceinline__ void as_dout_frags(short8_t (&f)[4], const AttnSeqParams& p, long tok, int col0, bool live, int lg) {
 #pragma unroll
-  for (int kk = 0; kk < 4; ++kk) {
-    f[kk] = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
-    if (!live) continue;
-    const int col = col0 + kk * 32 + lg * 8;
-    if (p.dout_bf && p.nslab <= 1) {
-      f[kk] = *reinterpret_cast<const short8_t*>(p.dout_bf + tok * p.ldd + col);
-    } else if (p.dout_bf) {                          // bf16 partial slabs: summed in fp32 in slab order, rounded once
-      const bf16_t* src = p.dout_bf + tok * p.ldd + col;
-      float v[8];
-      const short8_t h0 = *reinterpret_cast<const short8_t*>(src);            // one 16-byte load per slab
+  for (int kk = 0; kk < 4; ++kk) f[kk] = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
+  if (!live) return;
+  const int col = col0 + lg * 8;
+  // Every load of a round is issued before the first add: a loop over the slabs with a load and an add per turn is one memory
+  // latency per slab and per 32-column group (12 rounds for the step's 3 slabs, 32 for the batch-1 step's 8 -- it was a third
+  // to a half of this kernel, tools/attn_seq_phases.py).  The sums keep the slab order: v = slab 0, v += slab 1, ...
+  if (p.dout_bf && p.nslab <= 1) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[e] = bf2f((bf16_t)h0[e]);
-      for (int k = 1; k < p.nslab; ++k) {
-        const short8_t hk = *reinterpret_cast<const short8_t*>(src + (long)k * p.slab);
+    for (int kk = 0; kk < 4; ++kk) f[kk] = *reinterpret_cast<const short8_t*>(p.dout_bf + tok * p.ldd + col + kk * 32);
+  } else if (p.dout_bf) {                            // bf16 partial slabs: summed in fp32 in slab order, rounded once
+    const bf16_t* src = p.dout_bf + tok * p.ldd + col;
+    float v[4][8];
+    for (int k0 = 0; k0 < p.nslab; k0 += 4) {        // 4 slabs x 4 column groups = 16 loads of 16 bytes in flight
+      short8_t h[4][4];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += bf2f((bf16_t)hk[e]);
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          if (k0 + u < p.nslab) h[u][kk] = *reinterpret_cast<const short8_t*>(src + (long)(k0 + u) * p.slab + kk * 32);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (k0 + u >= p.nslab) continue;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float x = bf2f((bf16_t)h[u][kk][e]);
+            if (k0 + u == 0) v[kk][e] = x; else v[kk][e] += x;
+          }
       }
-      f[kk] = as_pack8((float4_t){v[0], v[1], v[2], v[3]}, (float4_t){v[4], v[5], v[6], v[7]});
-    } else {
-      const float* src = p.dout + tok * p.ldd + col;
-      float4_t a = *reinterpret_cast<const float4_t*>(src), c = *reinterpret_cast<const float4_t*>(src + 4);
-      for (int k = 1; k < p.nslab; ++k) {
-        const float4_t a2 = *reinterpret_cast<const float4_t*>(src + (long)k * p.slab);
-        const float4_t c2 = *reinterpret_cast<const float4_t*>(src + (long)k * p.slab + 4);
-        a[0] += a2[0]; a[1] += a2[1]; a[2] += a2[2]; a[3] += a2[3];
-        c[0] += c2[0]; c[1] += c2[1]; c[2] += c2[2]; c[3] += c2[3];
-      }
-      f[kk] = as_pack8(a, c);
     }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      f[kk] = as_pack8((float4_t){v[kk][0], v[kk][1], v[kk][2], v[kk][3]}, (float4_t){v[kk][4], v[kk][5], v[kk][6], v[kk][7]});
+  } else {
+    const float* src = p.dout + tok * p.ldd + col;
+    float4_t a[4], c[4];
+    for (int k0 = 0; k0 < p.nslab; k0 += 2) {        // 2 slabs x 4 column groups x 32 bytes in flight
+      float4_t a2[2][4], c2[2][4];
+#pragma unroll
+      for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+          if (k0 + u < p.nslab) {
+            a2[u][kk] = *reinterpret_cast<const float4_t*>(src + (long)(k0 + u) * p.slab + kk * 32);
+            c2[u][kk] = *reinterpret_cast<const float4_t*>(src + (long)(k0 + u) * p.slab + kk * 32 + 4);
+          }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (k0 + u >= p.nslab) continue;
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+          if (k0 + u == 0) { a[kk] = a2[u][kk]; c[kk] = c2[u][kk]; }
+          else {
+            a[kk][0] += a2[u][kk][0]; a[kk][1] += a2[u][kk][1]; a[kk][2] += a2[u][kk][2]; a[kk][3] += a2[u][kk][3];
+            c[kk][0] += c2[u][kk][0]; c[kk][1] += c2[u][kk][1]; c[kk][2] += c2[u][kk][2]; c[kk][3] += c2[u][kk][3];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) f[kk] = as_pack8(a[kk], c[kk]);
   }
 }
 
@@ -354,32 +390,50 @@ __global__ __launch_bounds__(AS_NW * 64) void attn_seq_bwd_kernel(AttnSeqParams 
   kv_valid = kv_valid < S ? kv_valid : S;
 
   const int rows = ((nf + 1) & ~1) * 16;
-  {
-    AsStage st;
-    as_stage_issue(st, kb, vb, p.ld, S, rows, pos);
-    as_stage_commit(st, I0, I1, S, rows, p.cos_tab, p.sin_tab);
+  AS_STAMP(0)
+  // Load order: everything this wave needs from global memory is requested before the first use -- the K / V rows of the
+  // staging, then this wave's own query rows (positions, Q, O), and only then the staging is committed (its rotary tables are a
+  // second, dependent round of loads) and the dO slabs are summed.  As separate load -> use -> load steps the prologue was 6-8
+  // memory latencies per owned fragment, two fragments back to back on the waves that own two (tools/attn_seq_phases.py).
+  // Two register sets (first / second owned fragment); the loops over fragments and key chunks below are rolled (see the forward
+  // kernel) and work on set 0, the sets are exchanged at the end of each fragment iteration.
+  short8_t qf0[4], gf0[4], qf1[4], gf1[4], of0[4], of1[4];
+  int ps0 = 0, ps1 = 0;
+  float dlt0 = 0.f, dlt1 = 0.f;
+  AsStage st;
+  as_stage_issue(st, kb, vb, p.ld, S, rows, pos);
+#pragma unroll
+  for (int which = 0; which < 2; ++which) {
+    short8_t (&qf)[4] = which ? qf1 : qf0;
+    short8_t (&of)[4] = which ? of1 : of0;
+    const int f = as_own(nf, wave, which);
+    const int qi = 16 * (f < 0 ? 0 : f) + lr;
+    const int row = f < 0 ? S : qi;                    // row >= S: as_row_frags returns zeros and loads nothing
+    if (row < S) { if (which) ps1 = pos[row]; else ps0 = pos[row]; }
+    as_row_frags<false>(qf, qb, p.ld, row, S, lg, pos, nullptr, nullptr);
+    as_row_frags<false>(of, p.o_in + (long)b * S * p.ldo + h * AS_D, p.ldo, row, S, lg, pos, nullptr, nullptr);
   }
+  as_stage_commit(st, I0, I1, S, rows, p.cos_tab, p.sin_tab);
+  AS_STAMP(1)
   for (int i = threadIdx.x; i < AS_MAXF * 16; i += AS_NW * 64) lse_s[i] = i < S ? p.lse[((long)b * p.H + h) * S + i] : 1e30f;
 
-  // this wave's query rows: Q (rotated), dO (slab sums) and delta, loaded while the images settle.  Two register sets
-  // (first / second owned fragment); the loops over fragments and key chunks are rolled (see the forward kernel) and work
-  // on set 0, the sets are exchanged at the end of each fragment iteration.
-  short8_t qf0[4], gf0[4], qf1[4], gf1[4];
-  float dlt0 = 0.f, dlt1 = 0.f;
 #pragma unroll
   for (int which = 0; which < 2; ++which) {
     short8_t (&qf)[4] = which ? qf1 : qf0;
     short8_t (&gf)[4] = which ? gf1 : gf0;
+    short8_t (&of)[4] = which ? of1 : of0;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) { qf[kk] = (short8_t){0, 0, 0, 0, 0, 0, 0, 0}; gf[kk] = qf[kk]; }
+    for (int kk = 0; kk < 4; ++kk) gf[kk] = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
     const int f = as_own(nf, wave, which);
     if (f < 0) continue;
     const int qi = 16 * f + lr;
-    as_row_frags<true>(qf, qb, p.ld, qi, S, lg, pos, p.cos_tab, p.sin_tab);
     as_dout_frags(gf, p, (long)b * S + qi, h * AS_D, qi < S, lg);
+    if (qi < S) {                                      // rotary on the Q rows: as_row_frags<true>'s expression
+      const int ps = which ? ps1 : ps0;
+      as_rope_pair(qf[0], qf[2], p.cos_tab + (size_t)ps * 64 + lg * 8, p.sin_tab + (size_t)ps * 64 + lg * 8, 1.f);
+      as_rope_pair(qf[1], qf[3], p.cos_tab + (size_t)ps * 64 + 32 + lg * 8, p.sin_tab + (size_t)ps * 64 + 32 + lg * 8, 1.f);
+    }
     // delta = sum_d dO * O over this lane's columns, combined across the row's four lanes
-    short8_t of[4];
-    as_row_frags<false>(of, p.o_in + (long)b * S * p.ldo + h * AS_D, p.ldo, qi, S, lg, pos, nullptr, nullptr);
     float dlt = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk)
@@ -390,13 +444,18 @@ __global__ __launch_bounds__(AS_NW * 64) void attn_seq_bwd_kernel(AttnSeqParams 
     if (lg == 0) dlt_s[qi] = dlt;
     if (which) dlt1 = dlt; else dlt0 = dlt;
   }
+  AS_STAMP(2)
   __syncthreads();
+  AS_STAMP(3)
 
+  // Small batches (B * H <= 128 workgroups would leave half the chip idle): the launch is two workgroups per (batch, head),
+  // blockIdx.y = 0 computes dq (phase A), 1 computes dk | dv (phase B); both stage K / V and build delta for every row.
+  const bool run_a = gridDim.y == 1 || blockIdx.y == 0, run_b = gridDim.y == 1 || blockIdx.y == 1;
   // ---------------- phase A
 #pragma unroll 1
   for (int which = 0; which < 2; ++which) {
     const int f = as_own(nf, wave, which);
-    if (f >= 0) {
+    if (f >= 0 && run_a) {
       const int qi = 16 * f + lr;
       const float dlt = dlt0, lse = lse_s[qi];
       float4_t acc[8];
@@ -443,6 +502,8 @@ __global__ __launch_bounds__(AS_NW * 64) void attn_seq_bwd_kernel(AttnSeqParams 
     }
     const float td = dlt0; dlt0 = dlt1; dlt1 = td;
   }
+  AS_STAMP(4)
+  if (!run_b) return;                                  // uniform over the workgroup: no barrier is skipped by part of it
   // ---------------- swap the images: keys' rows -> registers, queries' rows -> LDS
   short8_t kf0[4], vf0[4], kf1[4], vf1[4];
 #pragma unroll
@@ -474,6 +535,7 @@ __global__ __launch_bounds__(AS_NW * 64) void attn_seq_bwd_kernel(AttnSeqParams 
     }
   }
   __syncthreads();
+  AS_STAMP(5)
   // ---------------- phase B
 #pragma unroll 1
   for (int which = 0; which < 2; ++which) {
@@ -529,6 +591,7 @@ __global__ __launch_bounds__(AS_NW * 64) void attn_seq_bwd_kernel(AttnSeqParams 
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) { kf0[kk] = kf1[kk]; vf0[kk] = vf1[kk]; }
   }
+  AS_STAMP(6)
 }
 
 // ------------------------------------------------------------------------------------------- C ABI
@@ -579,6 +642,9 @@ extern "C" int mh_attn_rope_bwd(const void* qkv, int ld, const void* o, int ldo,
 
 extern "C" int mh_attn_rope_supported(int S, int D) { return (D == AS_D && S > 0 && S <= AS_MAXF * 16) ? 1 : 0; }
 
+static long long* g_as_trace = nullptr;
+extern "C" void mhdbg_set_attn_seq_trace(void* ptr) { g_as_trace = (long long*)ptr; }   // debug hook, not part of the ABI
+
 int mh_launch_attn_rope_bwd(const void* qkv, int ld, const void* o, int ldo, const void* dout, int dout_is_bf16, int nslab,
                             long slab, int ldd, const float* lse, void* dqkv, const int* pos, const float* cos_tab,
                             const float* sin_tab, const int* kv_len, int B, int H, int S, int D, float scale,
@@ -593,12 +659,16 @@ int mh_launch_attn_rope_bwd(const void* qkv, int ld, const void* o, int ldo, con
   p.scale = scale; p.dqkv = (bf16_t*)dqkv; p.nslab = nslab; p.slab = slab; p.ldd = ldd;
   if (dout_is_bf16) p.dout_bf = (const bf16_t*)dout;
   else p.dout = (const float*)dout;
+  p.trace = g_as_trace;
   static bool attr = false;
   if (!attr) {
     (void)hipFuncSetAttribute((const void*)attn_seq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)as_lds_bytes(true));
     attr = true;
   }
-  hipLaunchKernelGGL(attn_seq_bwd_kernel, dim3(B * H), dim3(AS_NW * 64), as_lds_bytes(true), stream, p);
+  static int split_mode = -1;                          // MYRIAD_ATTN_BWD_SPLIT=0 keeps one workgroup per (batch, head) (A/B runs)
+  if (split_mode < 0) { const char* e = getenv("MYRIAD_ATTN_BWD_SPLIT"); split_mode = (e && e[0] == '0') ? 0 : 1; }
+  const int parts = (split_mode && B * H <= 128) ? 2 : 1;
+  hipLaunchKernelGGL(attn_seq_bwd_kernel, dim3(B * H, parts), dim3(AS_NW * 64), as_lds_bytes(true), stream, p);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

@@ -10,7 +10,8 @@ dev = "cuda:0"
 cfg = full_config(llm_layers=1, vit_depth=1)
 m = MyriadHIP(SyntheticWeights(cfg, dev, seed=0), dict(need_backward=True), device=dev)
 qf = m.qformer
-for B in (1, 8):
+import os as _os
+for B in ([int(_os.environ['PROBE_B'])] if _os.environ.get('PROBE_B') else (1, 8)):
     q = torch.randn(B, 81, qf.D, device=dev)
     enc = torch.randn(B, 257, 1408, device=dev).to(torch.bfloat16)
     def run():

@@ -180,19 +180,31 @@ __global__ __launch_bounds__(AS_NW * 64) void attn_seq_fwd_kernel(AttnSeqParams 
   kv_valid = kv_valid < S ? kv_valid : S;
 
   const int rows = ((nf + 1) & ~1) * 16;
+  // this wave's query rows: their positions and raw values are requested right behind the staging's K / V rows, before the
+  // staging is committed (its rotary tables are a second, dependent round of loads); rotated afterwards -- as_row_frags<true>'s
+  // expression.  The loops below are ROLLED on purpose: the first version unrolled fragments x key chunks into 37 KB (forward) /
+  // 90 KB (backward) of straight-line code that every workgroup executes exactly once -- instruction-fetch bound (55-60 us per
+  // workgroup even on an idle chip).
+  short8_t qa[4], qn[4];
   {
     AsStage st;
     as_stage_issue(st, kb, vb, p.ld, S, rows, pos);
-    as_stage_commit(st, Ks, Vs, S, rows, p.cos_tab, p.sin_tab);
-  }
-  // this wave's query rows (rotated), loaded while the images settle.  The loops below are ROLLED on purpose: the first
-  // version unrolled fragments x key chunks into 37 KB (forward) / 90 KB (backward) of straight-line code that every
-  // workgroup executes exactly once -- instruction-fetch bound (55-60 us per workgroup even on an idle chip).
-  short8_t qa[4], qn[4];
-  {
     const int f0 = as_own(nf, wave, 0), f1 = as_own(nf, wave, 1);
-    if (f0 >= 0) as_row_frags<true>(qa, qb, p.ld, 16 * f0 + lr, S, lg, pos, p.cos_tab, p.sin_tab);
-    if (f1 >= 0) as_row_frags<true>(qn, qb, p.ld, 16 * f1 + lr, S, lg, pos, p.cos_tab, p.sin_tab);
+    const int r0 = f0 >= 0 ? 16 * f0 + lr : S, r1 = f1 >= 0 ? 16 * f1 + lr : S;
+    int ps0 = 0, ps1 = 0;
+    if (r0 < S) ps0 = pos[r0];
+    if (r1 < S) ps1 = pos[r1];
+    as_row_frags<false>(qa, qb, p.ld, r0, S, lg, pos, nullptr, nullptr);
+    as_row_frags<false>(qn, qb, p.ld, r1, S, lg, pos, nullptr, nullptr);
+    as_stage_commit(st, Ks, Vs, S, rows, p.cos_tab, p.sin_tab);
+    if (r0 < S) {
+      as_rope_pair(qa[0], qa[2], p.cos_tab + (size_t)ps0 * 64 + lg * 8, p.sin_tab + (size_t)ps0 * 64 + lg * 8, 1.f);
+      as_rope_pair(qa[1], qa[3], p.cos_tab + (size_t)ps0 * 64 + 32 + lg * 8, p.sin_tab + (size_t)ps0 * 64 + 32 + lg * 8, 1.f);
+    }
+    if (r1 < S) {
+      as_rope_pair(qn[0], qn[2], p.cos_tab + (size_t)ps1 * 64 + lg * 8, p.sin_tab + (size_t)ps1 * 64 + lg * 8, 1.f);
+      as_rope_pair(qn[1], qn[3], p.cos_tab + (size_t)ps1 * 64 + 32 + lg * 8, p.sin_tab + (size_t)ps1 * 64 + 32 + lg * 8, 1.f);
+    }
   }
   __syncthreads();
 

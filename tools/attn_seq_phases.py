@@ -45,3 +45,8 @@ for _ in range(20):
     ops.attn_rope_bwd(qkv, o, do, lse, H, D, scale, pos, cos, sin)
 e1.record(); torch.cuda.synchronize()
 print(f"attn_rope_bwd alone (bf16 dO): {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per launch")
+e0.record()
+for _ in range(20):
+    ops.attn_rope_fwd(qkv, H, D, scale, pos, cos, sin)
+e1.record(); torch.cuda.synchronize()
+print(f"attn_rope_fwd: {e0.elapsed_time(e1) / 20 * 1e3:.1f} us per launch")

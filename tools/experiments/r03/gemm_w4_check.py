@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Four-wave 256 x 256 GEMM instance (csrc/gemm_w4.hip) against the eight-wave kernel: bits and time, cold weights."""
+"""(To run: copy gemm_w4.hip into myriad_amd/csrc/, add "gemm_w4" to build.SOURCES, rebuild.)  Four-wave 256 x 256 GEMM instance (csrc/gemm_w4.hip) against the eight-wave kernel: bits and time, cold weights."""
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Knock-out timing of gemm_256_kernel's main loop (MYRIAD_G2_KO, WRONG RESULTS by construction): 8192^3 and 1184x22016x4096."""
+"""(Needs the MYRIAD_G2_KO knock-out instantiations, which were an experiment-only edit of gemm_256.hip: template <bool TRACE, int KO>, bits 1 no LDS-DMA in the loop, 2 no fragment reads, 4 no barrier, 8 no MFMA, 16 whole-line address pattern.)  Knock-out timing of gemm_256_kernel's main loop (MYRIAD_G2_KO, WRONG RESULTS by construction): 8192^3 and 1184x22016x4096."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

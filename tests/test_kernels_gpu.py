@@ -495,6 +495,31 @@ def test_attention_rope_whole_sequence(B, H, S, ragged, border):
         assert relerr(got[valid], want_tok[valid]) < 2.5e-2, nm
 
 
+def test_attention_rope_bwd_two_workgroups_per_head_same_bits():
+    """Small batches run the LLaMA attention backward as two workgroups per (batch, head) (dq | dk, dv): the same bits as one."""
+    import ctypes
+    from myriad_amd import _lib
+    lib = _lib.load()
+    lib.mhdbg_set_attn_bwd_split.argtypes = [ctypes.c_int]
+    lib.mhdbg_set_attn_bwd_split.restype = None
+    B, H, S, D = 2, 4, 148, 128
+    W = H * D
+    qkv = bf(rnd(B, S, 3 * W, seed=61)).to(DEV)
+    cos, sin = _rope_tables(D)
+    pos = torch.arange(S, dtype=torch.int32).repeat(B).to(DEV)
+    scale = D ** -0.5
+    o, lse = ops.attn_rope_fwd(qkv, H, D, scale, pos, cos, sin)
+    dout = bf(rnd(B, S, W, seed=62)).to(DEV)
+    try:
+        lib.mhdbg_set_attn_bwd_split(0)
+        one = ops.attn_rope_bwd(qkv, o, dout, lse, H, D, scale, pos, cos, sin).clone()
+        lib.mhdbg_set_attn_bwd_split(1)
+        two = ops.attn_rope_bwd(qkv, o, dout, lse, H, D, scale, pos, cos, sin).clone()
+    finally:
+        lib.mhdbg_set_attn_bwd_split(1)
+    assert torch.equal(one, two)
+
+
 def test_gemm_attention_rope_bwd_reads_split_k_slabs():
     """mh_gemm_attn_rope_bwd: the o_proj dgrad's split-K slabs summed inside the attention backward == gemm + attn_rope_bwd."""
     ops.ensure_workspace(torch.device(DEV))

@@ -126,6 +126,23 @@ def test_gemm_auto_splitk_epilogue(M, N, K, slab_bf16):
         hook(1)
 
 
+@pytest.mark.parametrize("M,N,K", [(648, 768, 768), (81, 768, 2304), (81, 3072, 768), (257, 1408, 1408), (196, 2368, 1024), (37, 100, 256)])
+def test_small_grid_instances_of_the_gemm_are_bit_identical(M, N, K):
+    """The policy's choice for one-round short-K grids (plan kernel 6: 64 x 64 tiles, 8-deep ring) and the other unsplit instances of
+    gemm_nt_kernel (128 x 128, 128 x 64, 6-deep 128 x 64) accumulate every output in the same k order: same bits, with every
+    epilogue form."""
+    assert ops.gemm_plan(M, N, K) == (6, 1)
+    a = bf(rnd(M, K, seed=21)).to(DEV)
+    b = bf(rnd(N, K, seed=22) * 0.05).to(DEV)
+    bias = rnd(N, seed=23).to(DEV)
+    res = rnd(M, N, seed=24).to(DEV)
+    auto_b, auto_f = ops.gemm(a, b, bias=bias, gelu=True), ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32)
+    assert relerr(auto_f, a.float() @ b.float().T + bias + res) < 1e-4
+    for v in (1, 3, 11, 13):
+        assert torch.equal(ops.gemm(a, b, bias=bias, gelu=True, variant=v), auto_b), v
+        assert torch.equal(ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32, variant=v), auto_f), v
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 12288, 4160), (16, 1000, 11008), (3, 32000, 4096)])
 def test_skinny_m_weight_streaming_gemm(M, N, K):
     """M <= 16 routes to the decode weight-streaming kernel (gemv.hip)."""

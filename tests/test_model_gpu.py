@@ -160,8 +160,9 @@ def test_llama_tiny_ragged_loss_grad_and_greedy_ids():
     e2 = emb.clone().requires_grad_(True)
     R.llama_causal_lm(sd, e2, g["mask"], g["labels"], heads)[0].backward()
     demb = lm.backward()
-    # tiny width (64) + std-0.2 weights amplify bf16 rounding: bound the max error at 12% and the Frobenius error at 5%
-    assert relerr(demb, e2.grad) < 1.2e-1
+    # tiny width (64) + std-0.2 weights amplify bf16 rounding: measured 7.5e-2 of max-abs on the worst element and 4.1e-2 in the
+    # Frobenius norm (deterministic); bounds 9e-2 / 5e-2.  The full-width model is held to 5e-2 of max-abs (below).
+    assert relerr(demb, e2.grad) < 9e-2
     assert ((demb.cpu() - e2.grad).norm() / e2.grad.norm()).item() < 5e-2
     # greedy decode with KV cache: ids equal to the oracle's wherever its margin is healthy
     with torch.no_grad():

@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libmyriad_hip.so")
-SOURCES = ["gemm", "gemm_256", "gemv", "decode_mega", "attention", "attn_seq", "norm", "elementwise", "conv", "loss", "lowrank", "lora", "expert", "image", "selfsup", "optim", "prof", "ctx", "version"]
+SOURCES = ["gemm", "gemm_256", "gemm_x4", "gemv", "decode_mega", "attention", "attn_seq", "norm", "elementwise", "conv", "loss", "lowrank", "lora", "expert", "image", "selfsup", "optim", "prof", "ctx", "version"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
 
 
@@ -25,6 +25,11 @@ def build(force: bool = False, verbose: bool = True) -> str:
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, "common.h")]
+    # the four-wave GEMM's K loop is written by a generator (the schedule lives there); regenerate when it is newer
+    gen, inc = os.path.join(CSRC, "gen_gemm_x4.py"), os.path.join(CSRC, "gemm_x4_loop.inc")
+    if force or _stale(inc, [gen]):
+        subprocess.check_call([sys.executable, gen])
+    hdrs.append(inc)
 
     def one(name):
         src = os.path.join(CSRC, name + ".hip")

@@ -389,6 +389,14 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(const bf16_t* __restri
 static long long* g2_trace = nullptr;
 extern "C" void mhdbg_set_gemm256_trace(void* p) { g2_trace = (long long*)p; }   // debug hook, not part of the ABI
 
+// Round 4: the same tile as a four-wave, 64-deep, hand-scheduled instruction stream (gemm_x4.hip) for launches with long K
+// per workgroup; both kernels produce the same bits.  Debug hook: 0 eight-wave, 1 four-wave, 2 / -1 the policy below.
+int mh_launch_gemm_x4(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
+                      const float* residual, int ldr, int flags, float alpha, int splits, int tps, long split_stride,
+                      hipStream_t stream, void* aux, int ldaux);
+static int g2_impl = -1;
+extern "C" void mhdbg_set_gemm256_impl(int impl) { g2_impl = impl; }   // debug hook (A/B tools, tests), not part of the ABI
+
 // tps / split_stride as in gemm.hip (tps in 64-deep K tiles)
 int mh_launch_gemm_256(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
                        const float* bias, const float* residual, int ldr, int flags, float alpha, int splits, int tps,
@@ -397,6 +405,15 @@ int mh_launch_gemm_256(const void* A, int lda, const void* B, int ldb, void* C, 
     // one 256-column tile = whole 128-column blocks; 16-byte rows; the fused forms never split K or take bias / residual
     if (!aux || splits != 1 || bias || residual || (flags & (MH_GEMM_OUT_F32 | MH_GEMM_GELU)) || (ldc & 7) || (ldaux & 7) || (N & 127))
       return MH_ERR_ARG;
+  }
+  // policy (tools/gemm_x4_sweep.py, K sweep on a one-round grid): the four-wave loop takes 1.29 us per 64-deep k-tile against
+  // 1.49, but its launch costs 17.7 us outside the loop against 11.9 (the first k-tile is a 64-KiB burst per CU and four waves
+  // drain the store tail instead of eight) -- it wins from ~30 k-tiles per workgroup.  MYRIAD_GEMM256_IMPL=0 / 1 forces one.
+  if (g2_impl < 0) { const char* e = getenv("MYRIAD_GEMM256_IMPL"); g2_impl = (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : 2; }
+  if ((g2_impl == 1 || (g2_impl == 2 && tps >= 32)) && !g2_trace) {
+    const int rc = mh_launch_gemm_x4(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, flags, alpha, splits, tps, split_stride,
+                                     stream, aux, ldaux);
+    if (rc != MH_ERR_UNSUPPORTED) return rc;
   }
   const int tiles_m = (M + G2_BM - 1) / G2_BM, tiles_n = (N + G2_BN - 1) / G2_BN;
   const size_t shmem = G2_NST * G2_STAGE;   // 128 KiB -> one 8-wave workgroup per CU

@@ -128,11 +128,8 @@ def round_up(x: int, m: int) -> int:
 
 
 # --------------------------------------------------------------------------- GEMM
-# Calibration switch, NOT a product path: MYRIAD_CALIB_LIB_GEMM=1 sends the plain unsplit 256-tile GEMMs (no epilogue, no K split:
-# at the bench shape the qkv and gate|up projections and the down projection's dgrad) to the vendor library through torch.matmul,
-# to measure what its kernel would buy at the step level (profiles/r03_gemm_experiments.md).  Off by default; the
-# shipped path is the hand-written kernel.
-_CALIB_LIB_GEMM = os.environ.get("MYRIAD_CALIB_LIB_GEMM", "0") == "1"
+# One GEMM backend: every product below is the library's own kernels.  (The vendor-library comparison lives in
+# tools/gemm_vendor_calib.py, outside the product.)
 
 
 def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, bias: Optional[torch.Tensor] = None,
@@ -151,9 +148,6 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, b
         _chk2d(out, out.dtype, "gemm.out")
         if out.shape != (M, N):
             raise _lib.MyriadHipError(f"gemm: out shape {tuple(out.shape)} != {(M, N)}")
-    if _CALIB_LIB_GEMM and variant < 0 and bias is None and residual is None and not gelu and not regstage and out.dtype == BF16 \
-            and alpha == 1.0 and gemm_plan(M, N, K) == (2, 1):
-        return torch.matmul(a, b.t(), out=out)          # CALIBRATION ONLY (see _CALIB_LIB_GEMM): the vendor library's GEMM
     flags = (GEMM_OUT_F32 if out.dtype == F32 else 0) | (GEMM_GELU if gelu else 0) | (GEMM_REGSTAGE if regstage else 0)
     flags |= (GEMM_VARIANT if variant < 0 else variant) << 8
     if bias is not None and (bias.dtype != F32 or bias.numel() != N):
@@ -528,9 +522,6 @@ def gemm_swiglu_fwd(x: torch.Tensor, wgu: torch.Tensor):
     _chk2d(wgu, BF16, "gemm_swiglu_fwd.wgu")
     M, K = x.shape
     I = wgu.shape[0] // 2
-    if _CALIB_LIB_GEMM and gemm_plan(M, 2 * I, K) == (2, 1):
-        gu = torch.matmul(x, wgu.t())                   # CALIBRATION ONLY
-        return gu, silu_mul_fwd_blk(gu)
     gu = torch.empty((M, 2 * I), dtype=BF16, device=x.device)
     act = torch.empty((M, I), dtype=BF16, device=x.device)
     rc = _L().mh_gemm_swiglu_fwd(_p(x), x.stride(0), _p(wgu), wgu.stride(0), _p(gu), 2 * I, _p(act), I, M, I, K, _s())
@@ -545,8 +536,6 @@ def gemm_swiglu_bwd(dh: torch.Tensor, wdT: torch.Tensor, gu: torch.Tensor):
     _chk2d(gu, BF16, "gemm_swiglu_bwd.gu")
     M, K = dh.shape
     I = wdT.shape[0]
-    if _CALIB_LIB_GEMM and gemm_plan(M, I, K) == (2, 1):
-        return silu_mul_bwd_blk(torch.matmul(dh, wdT.t()), gu)      # CALIBRATION ONLY
     dgu = torch.empty_like(gu)
     dact = torch.empty((M, I), dtype=BF16, device=dh.device)
     rc = _L().mh_gemm_swiglu_bwd(_p(dh), dh.stride(0), _p(wdT), wdT.stride(0), _p(gu), gu.stride(0), _p(dgu), dgu.stride(0),

@@ -143,6 +143,40 @@ def test_small_grid_instances_of_the_gemm_are_bit_identical(M, N, K):
         assert torch.equal(ops.gemm(a, b, bias=bias, residual=res, out_dtype=torch.float32, variant=v), auto_f), v
 
 
+@pytest.mark.parametrize("M,N,K,f32,hb,hr,alpha", [(256, 256, 64, 0, 0, 0, 1.0), (256, 256, 128, 1, 0, 0, 1.0), (300, 1000, 192, 0, 1, 0, 1.0),
+                                                  (300, 1000, 320, 0, 1, 0, 0.5), (1184, 4160, 2048, 1, 1, 1, 1.0), (1184, 4096, 12288, 0, 0, 0, 1.0),
+                                                  (520, 2176, 4096, 1, 0, 1, 0.25), (2056, 1408, 2112, 0, 1, 0, 1.0)])
+def test_four_wave_and_eight_wave_instances_of_the_256_tile_are_bit_identical(M, N, K, f32, hb, hr, alpha):
+    """gemm_x4.hip (four waves, 64-deep k-tiles, hand-scheduled loop: the policy's choice from 32 k-tiles per workgroup) and
+    gemm_256.hip (eight waves) accumulate every output in the same k order: same bits with every epilogue form, odd and even
+    k-tile counts (1, 2, 3, 5, ... k-tiles: the loop's one-tile, two-tile and steady paths), ragged M and N edges, K splits."""
+    import ctypes
+    from myriad_amd import _lib as L
+    hook = ctypes.CDLL(L.LIB_PATH).mhdbg_set_gemm256_impl
+    ops.ensure_workspace(torch.device(DEV))
+    a = bf(rnd(M, K, seed=31)).to(DEV)
+    b = bf(rnd(N, K, seed=32) * 0.05 + torch.arange(N)[:, None] * 1e-4).to(DEV)
+    bias = rnd(N, seed=33).to(DEV) if hb else None
+    res = rnd(M, N, seed=34).to(DEV) if hr else None
+    dt = torch.float32 if f32 else torch.bfloat16
+    ref = alpha * (a.float() @ b.float().T)
+    if hb:
+        ref = ref + bias
+    if hr:
+        ref = ref + res
+    outs = []
+    try:
+        for impl in (0, 1):
+            hook(impl)
+            out = torch.full((M, N), 7.0, dtype=dt, device=DEV)
+            ops.gemm(a, b, out=out, bias=bias, residual=res, alpha=alpha, variant=12)
+            outs.append(out)
+    finally:
+        hook(-1)
+    assert relerr(outs[1].float(), ref) < 6e-3        # bf16 output or bf16 split-K slabs; the claim here is the next line
+    assert torch.equal(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 12288, 4160), (16, 1000, 11008), (3, 32000, 4096)])
 def test_skinny_m_weight_streaming_gemm(M, N, K):
     """M <= 16 routes to the decode weight-streaming kernel (gemv.hip)."""

@@ -263,6 +263,9 @@ class MyriadHIP(nn.Module):
             self.lora = LoraQV(len(self.llama.layers), self.Dl, int(cfg.get("lora_r", 8)),
                                float(cfg.get("lora_alpha", 16)), float(cfg.get("lora_dropout", 0.05)),
                                self.store.p, self.store.g, self._dev)
+            # peft's nn.Dropout draws from torch's RNG, which train.py:63-72 seeds with seed + rank: the counter-based masks
+            # take that seed, so ranks (and runs with another seed) drop different elements (cfg lora_dropout_seed overrides)
+            self.lora.base_seed = int(cfg.get("lora_dropout_seed", torch.initial_seed())) & ((1 << 31) - 1)
             self.llama.attach_lora(self.lora)
         self._pending_update = None
         self._vit_stream, self._vit_prefetched = None, None

@@ -1,0 +1,78 @@
+"""Two data-parallel ranks of the HIP model on ONE GPU (the only N > 1 run a one-GPU box can make): SURVEY 8(e), reference
+runners/runner_base.py:94-98 (DDP, find_unused_parameters=True) + train.py:63-72 (seed + rank).  Two processes on cuda:0
+exchange the flat gradient buffer over gloo through runner.DataParallel with the overlap on (exchange on the side stream,
+AdamW delayed under the next step's look-ahead ViT); the result must be what ONE process gets from summing the two ranks'
+gradients and applying AdamW with 1/world -- bit for bit -- in both exchange modes."""
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _reference(dev):
+    """One process: per step, run both ranks' forward + backward (their batch, their prompt stage, their dropout seed), add the
+    two [gradients | use flags] buffers, one gated AdamW with grad_scale = 1/2."""
+    from tests import dp_common as C
+    model, cfg = C.build_model(dev)
+    st = model.store
+    losses = {0: [], 1: []}
+    for i in range(C.N_STEPS):
+        gsum = None
+        for r in (0, 1):
+            model.lora.base_seed = C.BASE_SEED + r
+            model.lora.step_seed = i                              # the training forward increments it: step i draws seed i + 1
+            model.fixed_stage = C.STAGES[r][i]
+            with torch.no_grad():
+                losses[r].append(float(model._forward_impl(C.batch(r, i, cfg["vocab"], dev), True)))
+                model.backward()
+                if model.use_lora:
+                    model.lora.join_wgrads()
+            torch.cuda.synchronize()
+            g = st.flat_g_comm.clone()
+            gsum = g if gsum is None else gsum + g
+        st.flat_g_comm.copy_(gsum)
+        st.adamw_step(C.LRS[i], 0.05, grad_scale=0.5)
+    return C.snapshot(model), losses
+
+
+@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
+def test_two_ranks_on_one_gpu_equal_one_process_summing_their_gradients(mode, tmp_path):
+    from tests import dp_common as C
+    port = str(29600 + (os.getpid() % 200) + (0 if mode == "allreduce" else 7))
+    outs = [str(tmp_path / f"rank{r}.pt") for r in (0, 1)]
+    env = dict(os.environ, PYTHONPATH=ROOT)
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), "2", port, mode, outs[r]],
+                              env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in (0, 1)]
+    logs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        logs.append(o.decode(errors="replace")[-3000:])
+    assert all(p.returncode == 0 for p in procs), "\n----\n".join(logs)
+    s0, s1 = (torch.load(o) for o in outs)
+    ref, ref_losses = _reference(torch.device("cuda:0"))
+    # the two ranks end with the same parameters and optimiser state
+    for k in ("p", "m", "v"):
+        assert torch.equal(s0[k], s1[k]), k
+    assert s0["steps"] == s1["steps"]
+    # ... which are the single-process result of averaging the two gradients
+    assert s0["losses"] == ref_losses[0] and s1["losses"] == ref_losses[1]
+    for k in ("p", "m", "v"):
+        assert torch.equal(s0[k], ref[k]), (k, (s0[k] - ref[k]).abs().max().item())
+    assert s0["steps"] == ref["steps"]
+    # a module no rank used in a step (VEInstructor at step 1) kept its step count: one update fewer than the others
+    assert s0["steps"]["VEInstructor"] == C.N_STEPS - 1 and s0["steps"]["VETokenizer"] == C.N_STEPS
+    assert s0["steps"]["expert_adaptor"] == C.N_STEPS and s0["steps"]["lora"] == C.N_STEPS
+    # and the parameters did move
+    model0, _ = C.build_model(torch.device("cuda:0"))
+    assert (model0.store.flat_p.cpu() - s0["p"]).abs().max().item() > 1e-5

@@ -257,21 +257,6 @@ int mh_gemv_packed_rmsnorm(const float* H, long ldh, const float* norm_w, float 
                            mh_stream_t s);
 int mh_gemv_packed_silu(const void* gu, long ldgu, const void* P, void* C, int ldc, int M, int N, int K, const float* bias,
                         const float* residual, int ldr, int out_f32, float alpha, mh_stream_t s);
-/* The whole token step of the decoder in ONE persistent launch (modeling_llama.py:184-299,564-604 with the KV cache) for 1-2
- * rows: per layer RMSNorm + q|k|v, rotary + KV append + attention, o_proj + residual, RMSNorm + gate|up, SiLU gate + down +
- * residual, then the final RMSNorm + lm_head -> logits [M, V] f32.  One 8-wave workgroup per CU, phases separated by a grid
- * barrier (agent-scope release / counter / acquire); before each barrier every wave requests the first 16 KiB of its next
- * phase's weights, so the HBM stream does not drain at phase boundaries the way it does at launch boundaries.  Bit-identical
- * to the separate launches.  layers: device array of n_layers records of 7 pointers {wqkv, wo, wgu, wd (mh_gemv_pack copies),
- * ln1, ln2 (f32), cache [B][T_cap][2D] bf16}; h: the embedded token on entry, the residual stream after (h2 its twin);
- * qkv / o / gu: scratch [M, 3D] / [M, D] / [M, 2I] bf16; bar: 1024 zeroed uint32 owned by the caller ([1] is raised if a
- * barrier ever times out: the step is then invalid); n_wg: workgroups = CUs certainly free (all must be resident).
- * MH_ERR_UNSUPPORTED outside M <= 2, head_dim 128, D <= 4096 (multiple of 1024), I % 128 == 0, LLaMA-7B-like block counts. */
-long mh_decode_mega_lds_bytes(int M, int D, int I, int T_cap);
-int mh_decode_mega(const void* layers, int n_layers, int M, int D, int H, int hd, int I, int V, int T_cap, float eps,
-                   float scale, float* h, float* h2, void* qkv, void* o, void* gu, const float* norm, const void* lm_head,
-                   float* logits, const int* pos, const int* pos_dev, const int* kvlen, const float* cos_tab,
-                   const float* sin_tab, long cache_bstride, long ld_cache, void* bar, int n_wg, mh_stream_t s);
 /* One decode token of attention (modeling_llama.py:186-222 with the KV cache): rotary on q / k, k | v appended at cache row
  * pos_dev[0], the one query against kv_len[b] keys -- mh_rope_kv_append + mh_attn_fwd(Sq = 1) in one launch, same bits.
  * qkv [B, ld_qkv] bf16 = [q | k | v] (q rotated in place), cache [B][T_cap][2 H D] rows [k | v], out [B, H D] bf16. */
@@ -361,6 +346,16 @@ int mh_ctx_comm_id(void* id128);
 int mh_ctx_comm_init(mh_ctx* ctx, const void* id128, int rank, int world);
 int mh_ctx_world(const mh_ctx* ctx);
 int mh_allreduce_start(mh_ctx* ctx, float* buf, long n, mh_stream_t producer);
+/* Round 4: wire type per call (MH_DT_F32 / MH_DT_BF16 elements) and the two halves of the sharded exchange
+ * (runner.DataParallel mode 'rs_ag': reduce-scatter the gradients, AdamW on the own 1/world shard, all-gather the parameters).
+ * mh_reduce_scatter_start: recv[0..n_per_rank) = sum over ranks of their send[rank * n_per_rank ..); send holds world *
+ * n_per_rank elements.  mh_allgather_start: recv[r * n_per_rank ..) = rank r's send[0..n_per_rank).  Verbs started back to
+ * back queue on the context's side stream; one mh_allreduce_wait covers everything started so far. */
+#define MH_DT_F32 0
+#define MH_DT_BF16 1
+int mh_allreduce_start_dt(mh_ctx* ctx, void* buf, long n, int dt, mh_stream_t producer);
+int mh_reduce_scatter_start(mh_ctx* ctx, const void* send, void* recv, long n_per_rank, int dt, mh_stream_t producer);
+int mh_allgather_start(mh_ctx* ctx, const void* send, void* recv, long n_per_rank, int dt, mh_stream_t producer);
 int mh_allreduce_wait(mh_ctx* ctx, mh_stream_t consumer);
 
 /* library identity */

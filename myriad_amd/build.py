@@ -10,7 +10,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(CSRC, "build")
 LIB = os.path.join(HERE, "libmyriad_hip.so")
-SOURCES = ["gemm", "gemm_256", "gemm_x4", "gemv", "decode_mega", "attention", "attn_seq", "norm", "elementwise", "conv", "loss", "lowrank", "lora", "expert", "image", "selfsup", "optim", "prof", "ctx", "version"]
+SOURCES = ["gemm", "gemm_256", "gemm_x4", "gemv", "attention", "attn_seq", "norm", "elementwise", "conv", "loss", "lowrank", "lora", "expert", "image", "selfsup", "optim", "prof", "ctx", "version"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
 
 

@@ -606,7 +606,9 @@ static void gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits) 
   const bool can_split = g_ws && (N % 4) == 0;
   {
     int k2, s2;
-    if (skinny_plan(M, N, K, can_split, &k2, &s2) && (size_t)s2 * M * N * sizeof(float) <= (g_ws_bytes ? g_ws_bytes : (size_t)-1)) {
+    // the scratch only has to hold the slabs of a launch that actually splits K (an unsplit 160-row launch was
+    // refused when the registered workspace was small)
+    if (skinny_plan(M, N, K, can_split, &k2, &s2) && (s2 == 1 || (size_t)s2 * M * N * sizeof(float) <= g_ws_bytes)) {
       *kernel = k2;
       *splits = s2;
       return;
@@ -634,7 +636,9 @@ static void gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits) 
   const long t128 = (long)((M + BM - 1) / BM) * ((N + 127) / 128);
   // < 256: the 128x128 grid would not give every CU a workgroup (round 3, tools/gemm_small_sweep.py: 2056x1408x1408, 187
   // tiles, 22.0 -> 17.9 us; 648x4096x768 15.1 -> 12.7 us; the bound was 160 before)
-  if (t128 * *splits < 256) *kernel = 3;
+  // unsplit only: a K-split launch of this policy branch runs on the 128x128 instance (run_splitk), and the plan says so
+  // (mh_gemm_plan and the profiler reported kernel 3 for a launch that ran kernel 1)
+  if (t128 * *splits < 256 && *splits == 1) *kernel = 3;
 }
 
 extern "C" int mh_gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits) {

@@ -164,8 +164,8 @@ class AnomalyDetectionDataset(Dataset):
                 src_index = int(self.rng.randint(len(self)))
             src = self._crop(src_index)
             ds, class_name = self.get_class_name(index)
-            args = self_sup.self_sup_args(ds, class_name)
-            if args.get("width_bounds_pct") is None or args.get("intensity_logistic_params") is None:
+            args = self_sup.self_sup_args(ds, class_name, visa_base="VISA" in self.ann_paths[0])
+            if ds == "mvtec" and (args.get("width_bounds_pct") is None or args.get("intensity_logistic_params") is None):
                 raise KeyError(f"MVTec class {class_name!r} is in neither argument table (the reference fails on the None it looks up)")
             if self.self_sup_mode is not None:
                 args.update(mode=self.self_sup_mode, resize=False)

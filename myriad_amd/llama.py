@@ -90,7 +90,6 @@ class LlamaHIP:
         # (55.7 -> 55.1 ms per step: they run beside the Q-Former backward); MYRIAD_LORA_DEFER=0 computes them in place
         self.defer_lora_wgrad = os.environ.get("MYRIAD_LORA_DEFER", "1") != "0"
         self.decode_fused = os.environ.get("MYRIAD_DECODE_FUSED", "1") != "0"
-        self.decode_mega = os.environ.get("MYRIAD_DECODE_MEGA", "0") == "1"
         self._packed = None
         self._decode_ws = {}
 
@@ -309,7 +308,6 @@ class LlamaHIP:
         calls generate() once per batch, and re-capturing ~290 launches each time cost ~9 ms per call."""
         T_cap = ops.round_up(T_need + 2, 64)
         key = (B, T_cap, float(inv_temp), id(self._packed), None if self._packed is None else self._packed.get("qkv_key"), self.decode_fused,
-               self.decode_mega,
                self.lora is not None)
         ws = self._decode_ws.get(key)
         if ws is None:
@@ -324,20 +322,6 @@ class LlamaHIP:
                       nxt=torch.empty((B,), dtype=torch.long, device=dev), mar=torch.empty((B,), dtype=F32, device=dev),
                       pmx=torch.empty((B,), dtype=F32, device=dev), step=torch.zeros((1,), dtype=i32, device=dev),
                       rec=torch.zeros((3, B), dtype=F32, device=dev))
-            if self.decode_mega and self._packed is not None and self.lora is None and B <= 2:
-                # the persistent token-step kernel's scratch and its per-layer pointer table (the KV caches belong to this workspace)
-                I = self.layers[0]["wd"].shape[1]
-                ptrs = []
-                for L, P, c in zip(self.layers, self._packed["layers"], ws["caches"]):
-                    ptrs += [P["wqkv"].data.data_ptr(), P["wo"].data.data_ptr(), P["wgu"].data.data_ptr(), P["wd"].data.data_ptr(),
-                             L["ln1"].data_ptr(), L["ln2"].data_ptr(), c.data_ptr()]
-                ws["mega"] = dict(table=torch.tensor(ptrs, dtype=torch.int64).to(dev), I=I,
-                                  h2=torch.empty((B, self.D), dtype=F32, device=dev),
-                                  qkv=torch.empty((B, 3 * self.D), dtype=BF16, device=dev),
-                                  o=torch.empty((B, self.D), dtype=BF16, device=dev),
-                                  gu=torch.empty((B, 2 * I), dtype=BF16, device=dev),
-                                  bar=torch.zeros((1024,), dtype=torch.int32, device=dev),
-                                  n_wg=torch.cuda.get_device_properties(dev).multi_processor_count)
             self._decode_ws[key] = ws
         return ws
 
@@ -437,16 +421,8 @@ class LlamaHIP:
 
         def token_step(ban):
             ops.embed_gather(self.embed, ws["ids"], ws["x_in"])
-            mg = ws.get("mega")
             done_lm = None
-            if mg is not None and ops.decode_mega(mg["table"], len(self.layers), B, self.D, self.H, self.hd, mg["I"], self.V, ws["T"],
-                                                  self.eps, scale, ws["x_in"], mg["h2"], mg["qkv"], mg["o"], mg["gu"], self.norm,
-                                                  self._packed["lm_head"], ws["logits"], ws["pos"], ws["pos"], ws["kvlen"], self.cos,
-                                                  self.sin, caches[0].stride(0), caches[0].stride(1), mg["bar"], mg["n_wg"]):
-                done_lm = True                              # the persistent kernel wrote the logits
-                hh = None
-            else:
-                hh = self._decode_block(ws["x_in"], B, 1, caches, scale, ws["pos"], pos_dev=ws["pos"], kvlen_dev=ws["kvlen"])
+            hh = self._decode_block(ws["x_in"], B, 1, caches, scale, ws["pos"], pos_dev=ws["pos"], kvlen_dev=ws["kvlen"])
             if done_lm is None and self._packed is not None and B <= 16 and self.decode_fused:
                 done_lm = ops.gemv_packed_rmsnorm(hh, self.norm, self.eps, self._packed["lm_head"], out=ws["logits"], out_dtype=F32)
             if done_lm is None:
@@ -486,8 +462,6 @@ class LlamaHIP:
             if redrawn and not done:
                 ws["ids"].copy_(out_ids[-1].to(self.dev))            # a host draw replaces the arg-max the step fed back to itself
             step += 1
-        if ws.get("mega") is not None and int(ws["mega"]["bar"][1]) != 0:
-            raise RuntimeError("mh_decode_mega: a grid barrier timed out (not every workgroup was resident); the generated ids are invalid")
         ids = torch.stack(out_ids, 1)
         if return_margins:
             return ids, torch.stack(margins, 1)

@@ -269,20 +269,6 @@ def attn_decode_rope(qkv2d: torch.Tensor, cache: torch.Tensor, pos: torch.Tensor
     return out
 
 
-def decode_mega(table: torch.Tensor, n_layers: int, M: int, D: int, H: int, hd: int, I: int, V: int, T_cap: int, eps: float,
-                scale: float, h, h2, qkv, o, gu, norm, lm_head: PackedWeight, logits, pos, pos_dev, kvlen, cos_tab, sin_tab,
-                cache_bs: int, ld_cache: int, bar, n_wg: int) -> bool:
-    """All decoder layers + final norm + lm_head of one token step as one persistent launch (mh_decode_mega).  False when
-    the shape is outside what the kernel covers (the caller then runs the per-op launches)."""
-    rc = _L().mh_decode_mega(_p(table), n_layers, M, D, H, hd, I, V, T_cap, float(eps), float(scale), _p(h), _p(h2), _p(qkv), _p(o),
-                             _p(gu), _p(norm), _p(lm_head.data), _p(logits), _p(pos), _p(pos_dev), _p(kvlen), _p(cos_tab), _p(sin_tab),
-                             int(cache_bs), int(ld_cache), _p(bar), int(n_wg), _s())
-    if rc == -3:
-        return False
-    _lib.check(rc, "mh_decode_mega")
-    return True
-
-
 def gemm_auto_f32(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
     """f32 out = a @ b^T, choosing split-K when the output is small and the reduction long (wgrad shapes)."""
     M, K = a.shape

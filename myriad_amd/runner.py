@@ -65,9 +65,12 @@ def setup_seeds(seed: int, rank: int = 0) -> None:
 
 
 class CtxCollective:
-    """The gradient all-reduce through the C ABI's context object (mh_ctx_*, mh_allreduce_start / _wait): RCCL communicator,
-    side stream and events live in the library; `start` orders the exchange behind the current stream and returns, `wait` makes
-    the current stream depend on it.  `dist` (any initialised process group) only carries the 128-byte communicator id."""
+    """The gradient exchange through the C ABI's context object (include/myriad_hip.h: mh_ctx_*, mh_allreduce_start_dt,
+    mh_reduce_scatter_start, mh_allgather_start, mh_allreduce_wait): RCCL communicator, side stream and events live in the
+    library; a `*_start` orders the verb behind the current stream and returns, `wait` makes the current stream depend on
+    everything started.  `dist` (any initialised process group) only carries the 128-byte communicator id."""
+
+    DT = {torch.float32: 0, torch.bfloat16: 1}
 
     def __init__(self, device, rank: int, world: int, dist=None):
         import ctypes
@@ -75,8 +78,10 @@ class CtxCollective:
         self.lib, self.check = _lib.load(), _lib.check
         self.dev = torch.device(device)
         h = ctypes.c_void_p()
-        self.check(self.lib.mh_ctx_create(ctypes.addressof(h)), "mh_ctx_create")
+        with torch.cuda.device(self.dev):                 # the context's side stream and events belong to THIS device
+            self.check(self.lib.mh_ctx_create(ctypes.addressof(h)), "mh_ctx_create")
         self.h = h
+        self.world = world
         idbuf = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             raw = (ctypes.c_ubyte * 128)()
@@ -89,14 +94,28 @@ class CtxCollective:
         raw = (ctypes.c_ubyte * 128)(*idbuf.tolist())
         with torch.cuda.device(self.dev):
             self.check(self.lib.mh_ctx_comm_init(self.h, ctypes.addressof(raw), rank, world), "mh_ctx_comm_init")
-        self.world = world
+
+    @staticmethod
+    def _s():
+        return torch.cuda.current_stream().cuda_stream
 
     def start(self, flat: torch.Tensor) -> None:
-        self.check(self.lib.mh_allreduce_start(self.h, flat.data_ptr(), flat.numel(), torch.cuda.current_stream().cuda_stream),
-                   "mh_allreduce_start")
+        """all-reduce(sum) in place, wire type = the tensor's dtype (f32 or bf16)."""
+        self.check(self.lib.mh_allreduce_start_dt(self.h, flat.data_ptr(), flat.numel(), self.DT[flat.dtype], self._s()),
+                   "mh_allreduce_start_dt")
+
+    def reduce_scatter(self, send: torch.Tensor, recv: torch.Tensor) -> None:
+        assert send.dtype == recv.dtype and send.numel() == recv.numel() * self.world
+        self.check(self.lib.mh_reduce_scatter_start(self.h, send.data_ptr(), recv.data_ptr(), recv.numel(), self.DT[send.dtype],
+                                                    self._s()), "mh_reduce_scatter_start")
+
+    def all_gather(self, send: torch.Tensor, recv: torch.Tensor) -> None:
+        assert send.dtype == recv.dtype and recv.numel() == send.numel() * self.world
+        self.check(self.lib.mh_allgather_start(self.h, send.data_ptr(), recv.data_ptr(), send.numel(), self.DT[send.dtype],
+                                               self._s()), "mh_allgather_start")
 
     def wait(self) -> None:
-        self.check(self.lib.mh_allreduce_wait(self.h, torch.cuda.current_stream().cuda_stream), "mh_allreduce_wait")
+        self.check(self.lib.mh_allreduce_wait(self.h, self._s()), "mh_allreduce_wait")
 
     def close(self) -> None:
         if self.h is not None:
@@ -136,14 +155,29 @@ class DataParallel:
             self.side = torch.cuda.Stream(device=device)
         self._pending = None
         self._bufs = {}
-        # MYRIAD_DP_COLLECTIVE=ctx: the all-reduce goes through the library's own verbs (mh_allreduce_start / _wait on an mh_ctx
-        # that owns an RCCL communicator and a side stream, include/myriad_hip.h) instead of torch.distributed; the process group
-        # is then only the channel that hands rank 0's communicator id to the other ranks.
+        # on RCCL (backend nccl) the exchange goes through the library's own verbs -- mh_allreduce_start_dt /
+        # mh_reduce_scatter_start / mh_allgather_start / mh_allreduce_wait on an mh_ctx that owns the communicator and the side
+        # stream (include/myriad_hip.h) -- both modes, both wire types; the process group is then only the channel that hands
+        # rank 0's communicator id to the other ranks.  torch.distributed carries the data on gloo (CPU tests, the one-GPU
+        # harness) or with MYRIAD_DP_COLLECTIVE=torch.  The context is checked once against the process group (a sum of ones):
+        # a build whose RCCL cannot be loaded or disagrees falls back to torch.distributed with a warning instead of failing the run.
         self.ctx = None
-        if (os.environ.get("MYRIAD_DP_COLLECTIVE") == "ctx" and self.world > 1 and device is not None
-                and torch.device(device).type == "cuda" and self.mode == "allreduce" and self.grad_dtype == torch.float32):
-            self.ctx = CtxCollective(device, self.rank, self.world, dist)
         self._gloo = dist.is_initialized() and dist.get_backend() == "gloo"
+        want = os.environ.get("MYRIAD_DP_COLLECTIVE", "ctx" if (dist.is_initialized() and dist.get_backend() == "nccl") else "torch")
+        if want == "ctx" and self.world > 1 and device is not None and torch.device(device).type == "cuda" and not self._gloo:
+            try:
+                ctx = CtxCollective(device, self.rank, self.world, dist)
+                probe = torch.ones(8, dtype=torch.float32, device=device)
+                ctx.start(probe)
+                ctx.wait()
+                torch.cuda.current_stream().synchronize()
+                if not bool((probe == float(self.world)).all()):
+                    raise RuntimeError(f"context all-reduce of ones gave {probe[0].item()} on {self.world} ranks")
+                self.ctx = ctx
+            except Exception as e:                          # noqa: BLE001 -- any failure here must not take the job down
+                import warnings
+                warnings.warn(f"mh_ctx gradient exchange unavailable ({e}); using torch.distributed")
+                self.ctx = None
 
     def _persistent(self, key: str, n: int, dtype, device) -> torch.Tensor:
         """Exchange staging buffers are allocated once per (purpose, size, dtype) and reused every step."""
@@ -209,8 +243,7 @@ class DataParallel:
         n_grad = flat_g_comm.numel() if n_grad is None else n_grad
 
         if self.ctx is not None:
-            self.ctx.start(flat_g_comm)
-            self._pending = True
+            self._ctx_start(flat_g_comm, n_grad)
             return
 
         def go():
@@ -226,9 +259,39 @@ class DataParallel:
             self._pending = ev if ev is not None else True
         self._run(go)
 
+    def _ctx_start(self, flat_g_comm: torch.Tensor, n_grad: int) -> None:
+        """The exchange through the library's verbs.  Casts (bf16 wire) run on the current stream in front of / behind the
+        verbs, which queue on the context's side stream; what has to happen after the wait is kept in self._pending."""
+        ctx, bf = self.ctx, self.grad_dtype == torch.bfloat16
+        after = []
+        if self.mode == "allreduce":
+            if bf:
+                w = self._cast(flat_g_comm, torch.bfloat16)
+                ctx.start(w)
+                after.append(lambda: flat_g_comm.copy_(self._cast(w, torch.float32)))
+            else:
+                ctx.start(flat_g_comm)
+        else:
+            if n_grad < flat_g_comm.numel():
+                ctx.start(flat_g_comm[n_grad:])                   # the use flags: a few floats, always fp32
+            body = flat_g_comm[:n_grad]
+            lo, hi, per = self.shard(n_grad)
+            if n_grad == per * self.world:                        # the store pads its buffers so that this holds at 2 / 4 / 8 ranks
+                padded = body
+            else:
+                padded = self._persistent("rs_pad", per * self.world, body.dtype, body.device)
+                padded[:n_grad].copy_(body)
+            w = self._cast(padded, self.grad_dtype)
+            mine = self._persistent("rs_mine", per, w.dtype, w.device)
+            ctx.reduce_scatter(w, mine)
+            after.append(lambda: body[lo:hi].copy_(self._cast(mine, body.dtype)[:hi - lo]))
+        self._pending = after
+
     def wait(self) -> None:
         if self._pending is not None and self.ctx is not None:
             self.ctx.wait()
+            for fn in self._pending:
+                fn()
             self._pending = None
             return
         if self._pending is not None:
@@ -246,6 +309,12 @@ class DataParallel:
             return
         n = flat_p.numel()
         lo, hi, per = self.shard(n)
+        if self.ctx is not None and n == per * self.world:
+            mine = self._persistent("ag_mine", per, flat_p.dtype, flat_p.device)
+            mine.copy_(flat_p[lo:hi])
+            self.ctx.all_gather(mine, flat_p)
+            self.ctx.wait()
+            return
         if self._gloo or n != per * self.world:
             mine = torch.zeros(per, dtype=flat_p.dtype, device=flat_p.device)
             mine[:hi - lo].copy_(flat_p[lo:hi])
@@ -267,6 +336,18 @@ class DataParallel:
     def barrier(self):
         if self.world > 1:
             self.dist.barrier()
+
+    def close(self) -> None:
+        """Release the context's communicator, stream and events (they leaked)."""
+        if self.ctx is not None:
+            self.ctx.close()
+            self.ctx = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:                                   # noqa: BLE001 -- interpreter shutdown
+            pass
 
 
 def init_distributed(backend: Optional[str] = None):

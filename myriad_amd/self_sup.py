@@ -47,15 +47,26 @@ MVTEC_BACKGROUND = {'bottle': (200, 60), 'screw': (200, 60), 'capsule': (200, 60
                     'pill': (20, 20), 'toothbrush': (20, 20), 'metal_nut': (20, 20)}
 
 
-def self_sup_args(dataset: str, class_name: str) -> dict:
-    """The keyword arguments `AnomalyDetectionDataset.__getitem__` passes to patch_ex (anomaly_detection.py:254-264):
-    dataset 'mvtec' -> the base set + that class's width bounds / logistic parameters / background (None for a class that is
-    not in a table, as dict.get gives); anything else -> the VisA set."""
+def self_sup_args(dataset: str, class_name: str, visa_base: Optional[bool] = None) -> dict:
+    """The keyword arguments `AnomalyDetectionDataset.__getitem__` passes to patch_ex (anomaly_detection.py:254-264), which are
+    two independent choices in the reference:
+      * the BASE set, fixed per dataset object by `'VISA' in ann_paths[0]` (anomaly_detection.py:118-141): the VisA set, else the
+        MVTec-style set WITHOUT width bounds / logistic parameters / resize bounds / background (patch_ex's own defaults apply);
+      * the per-item extras, by get_class_name's split (:224-230): 'mvtec' adds that class's width bounds / logistic parameters /
+        background (None for a class that is in no table, as dict.get gives); anything else adds nothing.
+    `visa_base=None` keeps the two tied (VisA base for a non-'mvtec' item), which is what every shipped annotation file gives.
+    A VisA base with MVTec extras passes width_bounds_pct twice in the reference (a TypeError there): the same error here."""
+    if visa_base is None:
+        visa_base = dataset != "mvtec"
+    base = dict(NSA_ARGS_VISA) if visa_base else dict(NSA_ARGS)
     if dataset == "mvtec":
-        return dict(NSA_ARGS, width_bounds_pct=MVTEC_WIDTH_BOUNDS_PCT.get(class_name),
+        if visa_base:
+            raise TypeError("patch_ex() got multiple values for keyword argument 'width_bounds_pct' (VisA base set + MVTec per-class "
+                            "arguments: anomaly_detection.py:118-141 with :254-259)")
+        base.update(width_bounds_pct=MVTEC_WIDTH_BOUNDS_PCT.get(class_name),
                     intensity_logistic_params=MVTEC_INTENSITY_LOGISTIC_PARAMS.get(class_name),
                     skip_background=MVTEC_BACKGROUND.get(class_name))
-    return dict(NSA_ARGS_VISA)
+    return base
 
 
 class PatchOp:

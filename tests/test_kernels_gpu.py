@@ -841,6 +841,27 @@ def test_context_object_owns_scratch_and_the_gradient_exchange():
         torch.cuda.synchronize()
         assert torch.equal(g, ref * 2.0 + 1.0)
         assert lib.mh_ctx_world(cc.h) == 1
+        # round 4: the other two verbs and the bf16 wire, through RCCL's own entry points on the one-rank communicator, queued
+        # back to back and covered by ONE wait -- the call sequence of runner.DataParallel mode 'rs_ag' (flags all-reduce,
+        # gradient reduce-scatter; later the parameter all-gather)
+        for dt in (torch.float32, torch.bfloat16):
+            src = rnd(1 << 18, seed=104).to(DEV).to(dt)
+            flags = rnd(8, seed=105).to(DEV)
+            f0 = flags.clone()
+            mine = torch.zeros_like(src)
+            back = torch.zeros_like(src)
+            cc.start(flags)
+            cc.reduce_scatter(src, mine)
+            cc.wait()
+            cc.all_gather(mine, back)
+            cc.wait()
+            torch.cuda.synchronize()
+            assert torch.equal(flags, f0) and torch.equal(mine, src) and torch.equal(back, src), dt
+            h = src.clone()
+            cc.start(h)                                                                          # all-reduce with this wire type
+            cc.wait()
+            torch.cuda.synchronize()
+            assert torch.equal(h, src), dt
     finally:
         lib.mh_ctx_make_current(None)
         cc.close()

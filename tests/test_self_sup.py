@@ -165,6 +165,16 @@ def test_dataset_arguments_follow_the_reference_tables():
     assert P.self_sup_args("mvtec", "carpet")["skip_background"] is None
     v = P.self_sup_args("visa", "candle")
     assert v["resize_bounds"] == (.5, 2) and v["width_bounds_pct"] == ((0.03, 0.4), (0.03, 0.4)) and v["intensity_logistic_params"] == (1 / 12, 24)
+    # an annotation file with neither tag: the MVTec-style base WITHOUT the VisA extras -- patch_ex's own defaults apply
+    # (anomaly_detection.py:118-141 picks the base by 'VISA' in ann_paths[0], :254-259 the extras by get_class_name)
+    n = P.self_sup_args("visa", "candle", visa_base=False)
+    assert "width_bounds_pct" not in n and "resize_bounds" not in n and "intensity_logistic_params" not in n and n["num_patches"] == 2
+    import inspect
+    d = {k: p.default for k, p in inspect.signature(P.plan).parameters.items()}
+    assert d["width_bounds_pct"] == ((0.05, 0.2), (0.05, 0.2)) and d["resize_bounds"] == (0.7, 1.3) and d["skip_background"] is None
+    assert inspect.signature(P.patch_ex).parameters["intensity_logistic_params"].default == (1 / 6, 20)
+    with pytest.raises(TypeError):
+        P.self_sup_args("mvtec", "screw", visa_base=True)
 
 
 def test_anomaly_detection_dataset_trains_with_the_reference_recipe(tmp_path):

@@ -406,11 +406,11 @@ int mh_launch_gemm_256(const void* A, int lda, const void* B, int ldb, void* C, 
     if (!aux || splits != 1 || bias || residual || (flags & (MH_GEMM_OUT_F32 | MH_GEMM_GELU)) || (ldc & 7) || (ldaux & 7) || (N & 127))
       return MH_ERR_ARG;
   }
-  // policy (tools/gemm_x4_sweep.py, K sweep on a one-round grid): the four-wave loop takes 1.29 us per 64-deep k-tile against
-  // 1.49, but its launch costs 17.7 us outside the loop against 11.9 (the first k-tile is a 64-KiB burst per CU and four waves
-  // drain the store tail instead of eight) -- it wins from ~30 k-tiles per workgroup.  MYRIAD_GEMM256_IMPL=0 / 1 forces one.
-  if (g2_impl < 0) { const char* e = getenv("MYRIAD_GEMM256_IMPL"); g2_impl = (e && (e[0] == '0' || e[0] == '1')) ? e[0] - '0' : 2; }
-  if ((g2_impl == 1 || (g2_impl == 2 && tps >= 32)) && !g2_trace) {
+  // policy (tools/gemm_x4_sweep.py, profiles/r04_gemm_x4.md): the hand-scheduled 64-deep loop (gemm_x4.hip, eight-wave form)
+  // is ahead of the kernel above on every shape of the step -- 1.31 against 1.49 us per 64-deep k-tile at the same ~13 us
+  // outside the loop -- so it takes every launch of plan kernel 2 it supports.  MYRIAD_GEMM256_IMPL=0 keeps the kernel above.
+  if (g2_impl < 0) { const char* e = getenv("MYRIAD_GEMM256_IMPL"); g2_impl = (e && e[0] == '0') ? 0 : 1; }
+  if (g2_impl != 0 && !g2_trace) {
     const int rc = mh_launch_gemm_x4(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, flags, alpha, splits, tps, split_stride,
                                      stream, aux, ldaux);
     if (rc != MH_ERR_UNSUPPORTED) return rc;

@@ -51,6 +51,168 @@ typedef __attribute__((ext_vector_type(4))) int int4v_t;
                  X4_CLOB8(3), X4_CLOB8(4), X4_CLOB8(5), X4_CLOB8(6), X4_CLOB8(7), X4_CLOB8(8), X4_CLOB8(9), X4_CLOB8(10),       \
                  X4_CLOB8(11), "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127")
 
+// Read-out of one 64 x 64 block of a wave's tile from its LDS slice `ep` ([64 rows][16 chunks of 16 B], chunk ^= row & 15, fp32,
+// un-scaled accumulators) to global memory, shared by the four- and eight-wave forms; the same expressions as gemm_256.hip's
+// epilogue (alpha applied here, on the way out of LDS).  mbase: global row of the block's row 0; wc: the block's 64-column
+// index inside the 256-column tile.  SwiGLU forward pairs the wave holding gate columns (slice g_slice) with the one holding
+// the matching up columns (g_slice + u_step); each turns rows pair_half * 32 .. + 31 into act columns (n0 / 2) + act_cb * 64 ..
+__device__ __forceinline__ void x_readout(char* smem, char* ep, int lane, int mbase, int wc, int n0, int g_slice, int u_step,
+                                          int pair_half, int act_cb, void* Cv, const float* bias, const float* res, int M, int N,
+                                          int ldc, int ldr, int flags, float alpha, void* aux, int ldaux) {
+  const bool out_f32 = flags & MH_GEMM_OUT_F32;
+  const bool do_gelu = flags & MH_GEMM_GELU;
+  const bool sw_fwd = flags & MH_GEMM_SWIGLU_FWD, sw_bwd = flags & MH_GEMM_SWIGLU_BWD;
+  const int er = lane >> 4, ec = lane & 15;
+  const int ncol = n0 + wc * 64 + ec * 4;
+  if (sw_bwd) {
+    const int r8 = lane >> 3, c8 = lane & 7;
+    const int nc = n0 + wc * 64 + c8 * 8;
+    const long gcol = (long)(nc >> 7) * 256 + (nc & 127);
+    const bf16_t* gu_in = reinterpret_cast<const bf16_t*>(aux);
+    bf16_t* dgu = reinterpret_cast<bf16_t*>(Cv);
+#pragma unroll 4
+    for (int p = 0; p < 8; ++p) {
+      const int row = p * 8 + r8;
+      const int m = mbase + row;
+      const float4_t va = *reinterpret_cast<const float4_t*>(ep + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
+      const float4_t vb = *reinterpret_cast<const float4_t*>(ep + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
+      if (m >= M || nc >= N) continue;
+      const float v[8] = {va[0] * alpha, va[1] * alpha, va[2] * alpha, va[3] * alpha,
+                          vb[0] * alpha, vb[1] * alpha, vb[2] * alpha, vb[3] * alpha};
+      const short8_t g8 = *reinterpret_cast<const short8_t*>(gu_in + (size_t)m * ldaux + gcol);
+      const short8_t u8 = *reinterpret_cast<const short8_t*>(gu_in + (size_t)m * ldaux + gcol + 128);
+      short8_t og, ou;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float gv = bf2f((bf16_t)g8[e]), uv = bf2f((bf16_t)u8[e]), dv = bf2f(f2bf(v[e]));
+        const float sg = 1.f / (1.f + __expf(-gv));
+        const float silu = gv * sg;
+        og[e] = (short)f2bf(dv * uv * (sg + silu * (1.f - sg)));
+        ou[e] = (short)f2bf(dv * silu);
+      }
+      *reinterpret_cast<short8_t*>(dgu + (size_t)m * ldc + gcol) = og;
+      *reinterpret_cast<short8_t*>(dgu + (size_t)m * ldc + gcol + 128) = ou;
+    }
+    return;
+  }
+  if (sw_fwd) {
+    // wave (wm, 0) holds gate columns, (wm, 1) the matching up columns of this 64 x 64 block: each of the pair turns 32
+    // of the 64 rows into act = silu(g) * u
+    __syncthreads();
+    const int r8 = lane >> 3, c8 = lane & 7;
+    const char* sg_ = smem + g_slice * 16384;
+    const char* su_ = smem + (g_slice + u_step) * 16384;
+    bf16_t* act = reinterpret_cast<bf16_t*>(aux);
+    const int ac = (n0 >> 1) + act_cb * 64 + c8 * 8;
+#pragma unroll 4
+    for (int p = 0; p < 4; ++p) {
+      const int row = pair_half * 32 + p * 8 + r8;
+      const int m = mbase + row;
+      const int o0 = row * 256 + (((2 * c8) ^ (row & 15)) << 4), o1 = row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4);
+      const float4_t ga = *reinterpret_cast<const float4_t*>(sg_ + o0), gb = *reinterpret_cast<const float4_t*>(sg_ + o1);
+      const float4_t ua = *reinterpret_cast<const float4_t*>(su_ + o0), ub = *reinterpret_cast<const float4_t*>(su_ + o1);
+      if (m >= M || ac >= (N >> 1)) continue;
+      const float gg[8] = {ga[0], ga[1], ga[2], ga[3], gb[0], gb[1], gb[2], gb[3]};
+      const float uu[8] = {ua[0], ua[1], ua[2], ua[3], ub[0], ub[1], ub[2], ub[3]};
+      short8_t o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float gv = bf2f(f2bf(gg[e] * alpha)), uv = bf2f(f2bf(uu[e] * alpha));
+        o[e] = (short)f2bf(gv / (1.f + __expf(-gv)) * uv);
+      }
+      *reinterpret_cast<short8_t*>(act + (size_t)m * ldaux + ac) = o;
+    }
+  }
+  if (!out_f32 && (ldc & 7) == 0) {
+    const int r8 = lane >> 3, c8 = lane & 7;
+    const int nc = n0 + wc * 64 + c8 * 8;
+#pragma unroll 4
+    for (int p = 0; p < 8; ++p) {
+      const int row = p * 8 + r8;
+      const int m = mbase + row;
+      const float4_t va = *reinterpret_cast<const float4_t*>(ep + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
+      const float4_t vb = *reinterpret_cast<const float4_t*>(ep + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
+      if (m >= M || nc >= N) continue;
+      float v[8] = {va[0] * alpha, va[1] * alpha, va[2] * alpha, va[3] * alpha,
+                    vb[0] * alpha, vb[1] * alpha, vb[2] * alpha, vb[3] * alpha};
+      if (nc + 7 < N) {
+        if (bias) {
+          const float4_t b0 = *reinterpret_cast<const float4_t*>(bias + nc);
+          const float4_t b1 = *reinterpret_cast<const float4_t*>(bias + nc + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
+        }
+        if (do_gelu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (res) {
+          const float4_t q0 = *reinterpret_cast<const float4_t*>(res + (size_t)m * ldr + nc);
+          const float4_t q1 = *reinterpret_cast<const float4_t*>(res + (size_t)m * ldr + nc + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += q0[e]; v[4 + e] += q1[e]; }
+        }
+        uint4 pk;
+        pk.x = pack_bf2(v[0], v[1]);
+        pk.y = pack_bf2(v[2], v[3]);
+        pk.z = pack_bf2(v[4], v[5]);
+        pk.w = pack_bf2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(Cv) + (size_t)m * ldc + nc) = pk;
+      } else {
+        for (int e = 0; e < 8 && nc + e < N; ++e) {
+          float x = v[e];
+          if (bias) x += bias[nc + e];
+          if (do_gelu) x = gelu_erf(x);
+          if (res) x += res[(size_t)m * ldr + nc + e];
+          reinterpret_cast<bf16_t*>(Cv)[(size_t)m * ldc + nc + e] = f2bf(x);
+        }
+      }
+    }
+    if (sw_fwd) __syncthreads();                     // the partner has read this slice before the next block overwrites it
+    return;
+  }
+#pragma unroll 4
+  for (int p = 0; p < 16; ++p) {
+    const int row = p * 4 + er;
+    const int m = mbase + row;
+    const float4_t v4 = *reinterpret_cast<const float4_t*>(ep + row * 256 + ((ec ^ (row & 15)) << 4));
+    if (m >= M || ncol >= N) continue;
+    float v[4] = {v4[0] * alpha, v4[1] * alpha, v4[2] * alpha, v4[3] * alpha};
+    if (ncol + 3 < N) {
+      if (bias) {
+        const float4_t b4 = *reinterpret_cast<const float4_t*>(bias + ncol);
+        v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+      }
+      if (do_gelu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+      }
+      if (res) {
+        const float4_t r4 = *reinterpret_cast<const float4_t*>(res + (size_t)m * ldr + ncol);
+        v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
+      }
+      if (out_f32) {
+        *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(Cv) + (size_t)m * ldc + ncol) =
+            (float4_t){v[0], v[1], v[2], v[3]};
+      } else {
+        uint2 pk;
+        pk.x = pack_bf2(v[0], v[1]);
+        pk.y = pack_bf2(v[2], v[3]);
+        *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (size_t)m * ldc + ncol) = pk;
+      }
+    } else {
+      for (int e = 0; e < 4 && ncol + e < N; ++e) {
+        float x = v[e];
+        if (bias) x += bias[ncol + e];
+        if (do_gelu) x = gelu_erf(x);
+        if (res) x += res[(size_t)m * ldr + ncol + e];
+        if (out_f32) reinterpret_cast<float*>(Cv)[(size_t)m * ldc + ncol + e] = x;
+        else reinterpret_cast<bf16_t*>(Cv)[(size_t)m * ldc + ncol + e] = f2bf(x);
+      }
+    }
+  }
+}
+
 template <int V>
 __global__ __launch_bounds__(256) void gemm_x4_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* Cv,
                                                       const float* __restrict__ bias, const float* res, int M, int N, int K,
@@ -113,21 +275,7 @@ __global__ __launch_bounds__(256) void gemm_x4_kernel(const bf16_t* __restrict__
     sb[2] = -1;
     sb[3] = 0x00020000;
     unsigned koff = (unsigned)kt0 * 128u, cnt = (unsigned)nt, wr = sbase + wave * 1024;
-    if constexpr (V == 0) { X4_ASM(X4_LOOP_0); }
-#if X4_NVARIANTS > 1   // tuning / knock-out schedules (gen_gemm_x4.py --sweep): not in the shipped library
-    else if constexpr (V == 1) { X4_ASM(X4_LOOP_1); }
-    else if constexpr (V == 2) { X4_ASM(X4_LOOP_2); }
-    else if constexpr (V == 3) { X4_ASM(X4_LOOP_3); }
-    else if constexpr (V == 4) { X4_ASM(X4_LOOP_4); }
-    else if constexpr (V == 5) { X4_ASM(X4_LOOP_5); }
-    else if constexpr (V == 6) { X4_ASM(X4_LOOP_6); }
-    else if constexpr (V == 7) { X4_ASM(X4_LOOP_7); }
-    else if constexpr (V == 8) { X4_ASM(X4_LOOP_8); }
-    else if constexpr (V == 9) { X4_ASM(X4_LOOP_9); }
-    else if constexpr (V == 10) { X4_ASM(X4_LOOP_10); }
-    else if constexpr (V == 11) { X4_ASM(X4_LOOP_11); }
-    else if constexpr (V == 12) { X4_ASM(X4_LOOP_12); }
-#endif
+    X4_DISPATCH4(V);
   }
 
   // ---- epilogue: the 128 x 128 wave tile leaves in four 64 x 64 blocks (column half cb, row half h), each transposed
@@ -138,11 +286,7 @@ __global__ __launch_bounds__(256) void gemm_x4_kernel(const bf16_t* __restrict__
   // v_accvgpr_read, SGPR spills: 21 us of fixed cost per launch against the eight-wave kernel's 10.6).  alpha is applied on
   // the way out of LDS (the same fp32 product).  The loop's last barrier sits after every wave's last fragment read and no
   // LDS-DMA is in flight (the tail iterations request nothing), so the buffers are free.
-  const bool out_f32 = flags & MH_GEMM_OUT_F32;
-  const bool do_gelu = flags & MH_GEMM_GELU;
-  const bool sw_fwd = flags & MH_GEMM_SWIGLU_FWD, sw_bwd = flags & MH_GEMM_SWIGLU_BWD;
   char* ep = smem + wave * 16384;                      // [64 rows][16 chunks of 16 B], chunk ^= row & 15
-  const int er = lane >> 4, ec = lane & 15;
   // fragment (ii, jj) of a block: row ii * 16 + lr, 16-byte chunk (jj * 4 + lg) ^ lr -> one address per jj, ii in the offset
   unsigned wa0, wa1, wa2, wa3;
   {
@@ -159,159 +303,112 @@ __global__ __launch_bounds__(256) void gemm_x4_kernel(const bf16_t* __restrict__
 #pragma unroll 1
   for (int blk = 0; blk < 4; ++blk) {
     const int cb = blk >> 1, h = blk & 1;
-    const int wc = wn * 2 + cb;                        // 64-column block of the tile, as gemm_256.hip numbers them
-    const int ncol = n0 + wc * 64 + ec * 4;
     if (blk == 0) X4_WRITE(X4_WR_0);
     else if (blk == 1) X4_WRITE(X4_WR_1);
     else if (blk == 2) X4_WRITE(X4_WR_2);
     else X4_WRITE(X4_WR_3);
-    if (sw_bwd) {
-      const int r8 = lane >> 3, c8 = lane & 7;
-      const int nc = n0 + wc * 64 + c8 * 8;
-      const long gcol = (long)(nc >> 7) * 256 + (nc & 127);
-      const bf16_t* gu_in = reinterpret_cast<const bf16_t*>(aux);
-      bf16_t* dgu = reinterpret_cast<bf16_t*>(Cv);
-#pragma unroll 4
-      for (int p = 0; p < 8; ++p) {
-        const int row = p * 8 + r8;
-        const int m = m0 + wm * 128 + h * 64 + row;
-        const float4_t va = *reinterpret_cast<const float4_t*>(ep + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
-        const float4_t vb = *reinterpret_cast<const float4_t*>(ep + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
-        if (m >= M || nc >= N) continue;
-        const float v[8] = {va[0] * alpha, va[1] * alpha, va[2] * alpha, va[3] * alpha,
-                            vb[0] * alpha, vb[1] * alpha, vb[2] * alpha, vb[3] * alpha};
-        const short8_t g8 = *reinterpret_cast<const short8_t*>(gu_in + (size_t)m * ldaux + gcol);
-        const short8_t u8 = *reinterpret_cast<const short8_t*>(gu_in + (size_t)m * ldaux + gcol + 128);
-        short8_t og, ou;
+    // 64-column block wn * 2 + cb of the tile, as gemm_256.hip numbers them; SwiGLU: wave (wm, 0) holds gate, (wm, 1) up columns
+    x_readout(smem, ep, lane, m0 + wm * 128 + h * 64, wn * 2 + cb, n0, wm * 2, 1, wn, cb, Cv, bias, res, M, N, ldc, ldr, flags,
+              alpha, aux, ldaux);
+  }
+}
+
+// ---- eight-wave form: 2 x 4 waves, 128 x 64 per wave (128 accumulators, 108 VGPRs: two waves per SIMD), the same buffers,
+// LDS image, request pattern (each wave issues 4 + 4 of the 64 requests of a k-tile) and loop structure at half the slots per
+// wave.  What one wave cannot hide under its own MFMAs -- the issue time of its LDS-DMA requests (~60 cycles each) and
+// fragment reads -- the SIMD's other wave fills (profiles/r04_gemm_x4.md: knock-outs of the four-wave loop).
+#define X8_ASM(LOOP)                                                                                                            \
+  asm volatile(LOOP                                                                                                             \
+               : "={a[0:31]}"(c[0]), "={a[32:63]}"(c[1]), "={a[64:95]}"(c[2]), "={a[96:127]}"(c[3]), "+{v104}"(ra0),            \
+                 "+{v105}"(ra1), "+{v106}"(rb0), "+{v107}"(rb1), "+{s44}"(koff), "+{s45}"(cnt), "+{s46}"(wr)                    \
+               : "{v[96:99]}"(voa), "{v[100:103]}"(vob), "{s[36:39]}"(sa), "{s[40:43]}"(sb)                                     \
+               : "memory", "scc", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", X4_CLOB8(1), X4_CLOB8(2),         \
+                 X4_CLOB8(3), X4_CLOB8(4), X4_CLOB8(5), X4_CLOB8(6), X4_CLOB8(7), X4_CLOB8(8), "v90", "v91", "v92", "v93",      \
+                 "v94", "v95")
+
+template <int V>
+__global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ B, void* Cv,
+                                                      const float* __restrict__ bias, const float* res, int M, int N, int K,
+                                                      int lda, int ldb, int ldc, int ldr, int flags, float alpha, int tiles_m,
+                                                      int kt_per_split, long split_stride, void* aux, int ldaux) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // [2 buffers][A 32K | B 32K]; reused by the epilogue
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int lr = lane & 15, lg = lane >> 4;
+
+  const int nwg = gridDim.x, bid = blockIdx.x;
+  const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int tiles_n = nwg / tiles_m;
+  const int per_group = 8 * tiles_n;
+  const int first_m = (lid / per_group) * 8;
+  const int gsz = (tiles_m - first_m) < 8 ? (tiles_m - first_m) : 8;
+  const int tm = first_m + (lid % per_group) % gsz, tn = (lid % per_group) / gsz;
+  const int m0 = tm * X4_BM, n0 = tn * X4_BN;
+
+  const int nt_all = K >> 6;
+  const int kt0 = blockIdx.y * kt_per_split;
+  const int nt = (nt_all - kt0) < kt_per_split ? (nt_all - kt0) : kt_per_split;
+  if (gridDim.y > 1)
+    Cv = (flags & MH_GEMM_OUT_F32) ? (void*)(reinterpret_cast<float*>(Cv) + blockIdx.y * split_stride)
+                                   : (void*)(reinterpret_cast<bf16_t*>(Cv) + blockIdx.y * split_stride);
+
+  float32_t c[4];
+  {
+    // request i of wave w stages rows (w + 8 i) * 8 + (lane >> 3); the swizzle term is again independent of i
+    int4v_t voa, vob;
+    const int swz = (4 * (wave & 1) + (lane >> 4)) & 7;
+    const int ch = ((lane & 7) ^ swz) << 4;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float gv = bf2f((bf16_t)g8[e]), uv = bf2f((bf16_t)u8[e]), dv = bf2f(f2bf(v[e]));
-          const float sg = 1.f / (1.f + __expf(-gv));
-          const float silu = gv * sg;
-          og[e] = (short)f2bf(dv * uv * (sg + silu * (1.f - sg)));
-          ou[e] = (short)f2bf(dv * silu);
-        }
-        *reinterpret_cast<short8_t*>(dgu + (size_t)m * ldc + gcol) = og;
-        *reinterpret_cast<short8_t*>(dgu + (size_t)m * ldc + gcol + 128) = ou;
-      }
-      continue;
+    for (int i = 0; i < 4; ++i) {
+      const int row = (wave + 8 * i) * 8 + (lane >> 3);
+      int ra = m0 + row, rb = n0 + row;
+      ra = ra < M ? ra : M - 1;
+      rb = rb < N ? rb : N - 1;
+      voa[i] = ra * lda * 2 + ch;
+      vob[i] = rb * ldb * 2 + ch;
     }
-    if (sw_fwd) {
-      // wave (wm, 0) holds gate columns, (wm, 1) the matching up columns of this 64 x 64 block: each of the pair turns 32
-      // of the 64 rows into act = silu(g) * u
-      __syncthreads();
-      const int r8 = lane >> 3, c8 = lane & 7;
-      const char* sg_ = smem + (wm * 2) * 16384;
-      const char* su_ = smem + (wm * 2 + 1) * 16384;
-      bf16_t* act = reinterpret_cast<bf16_t*>(aux);
-      const int ac = (n0 >> 1) + cb * 64 + c8 * 8;
-#pragma unroll 4
-      for (int p = 0; p < 4; ++p) {
-        const int row = wn * 32 + p * 8 + r8;
-        const int m = m0 + wm * 128 + h * 64 + row;
-        const int o0 = row * 256 + (((2 * c8) ^ (row & 15)) << 4), o1 = row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4);
-        const float4_t ga = *reinterpret_cast<const float4_t*>(sg_ + o0), gb = *reinterpret_cast<const float4_t*>(sg_ + o1);
-        const float4_t ua = *reinterpret_cast<const float4_t*>(su_ + o0), ub = *reinterpret_cast<const float4_t*>(su_ + o1);
-        if (m >= M || ac >= (N >> 1)) continue;
-        const float gg[8] = {ga[0], ga[1], ga[2], ga[3], gb[0], gb[1], gb[2], gb[3]};
-        const float uu[8] = {ua[0], ua[1], ua[2], ua[3], ub[0], ub[1], ub[2], ub[3]};
-        short8_t o;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float gv = bf2f(f2bf(gg[e] * alpha)), uv = bf2f(f2bf(uu[e] * alpha));
-          o[e] = (short)f2bf(gv / (1.f + __expf(-gv)) * uv);
-        }
-        *reinterpret_cast<short8_t*>(act + (size_t)m * ldaux + ac) = o;
-      }
-    }
-    if (!out_f32 && (ldc & 7) == 0) {
-      const int r8 = lane >> 3, c8 = lane & 7;
-      const int nc = n0 + wc * 64 + c8 * 8;
-#pragma unroll 4
-      for (int p = 0; p < 8; ++p) {
-        const int row = p * 8 + r8;
-        const int m = m0 + wm * 128 + h * 64 + row;
-        const float4_t va = *reinterpret_cast<const float4_t*>(ep + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
-        const float4_t vb = *reinterpret_cast<const float4_t*>(ep + row * 256 + (((2 * c8 + 1) ^ (row & 15)) << 4));
-        if (m >= M || nc >= N) continue;
-        float v[8] = {va[0] * alpha, va[1] * alpha, va[2] * alpha, va[3] * alpha,
-                      vb[0] * alpha, vb[1] * alpha, vb[2] * alpha, vb[3] * alpha};
-        if (nc + 7 < N) {
-          if (bias) {
-            const float4_t b0 = *reinterpret_cast<const float4_t*>(bias + nc);
-            const float4_t b1 = *reinterpret_cast<const float4_t*>(bias + nc + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += b0[e]; v[4 + e] += b1[e]; }
-          }
-          if (do_gelu) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
-          }
-          if (res) {
-            const float4_t q0 = *reinterpret_cast<const float4_t*>(res + (size_t)m * ldr + nc);
-            const float4_t q1 = *reinterpret_cast<const float4_t*>(res + (size_t)m * ldr + nc + 4);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { v[e] += q0[e]; v[4 + e] += q1[e]; }
-          }
-          uint4 pk;
-          pk.x = pack_bf2(v[0], v[1]);
-          pk.y = pack_bf2(v[2], v[3]);
-          pk.z = pack_bf2(v[4], v[5]);
-          pk.w = pack_bf2(v[6], v[7]);
-          *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(Cv) + (size_t)m * ldc + nc) = pk;
-        } else {
-          for (int e = 0; e < 8 && nc + e < N; ++e) {
-            float x = v[e];
-            if (bias) x += bias[nc + e];
-            if (do_gelu) x = gelu_erf(x);
-            if (res) x += res[(size_t)m * ldr + nc + e];
-            reinterpret_cast<bf16_t*>(Cv)[(size_t)m * ldc + nc + e] = f2bf(x);
-          }
-        }
-      }
-      if (sw_fwd) __syncthreads();                     // the partner has read this slice before the next block overwrites it
-      continue;
-    }
-#pragma unroll 4
-    for (int p = 0; p < 16; ++p) {
-      const int row = p * 4 + er;
-      const int m = m0 + wm * 128 + h * 64 + row;
-      const float4_t v4 = *reinterpret_cast<const float4_t*>(ep + row * 256 + ((ec ^ (row & 15)) << 4));
-      if (m >= M || ncol >= N) continue;
-      float v[4] = {v4[0] * alpha, v4[1] * alpha, v4[2] * alpha, v4[3] * alpha};
-      if (ncol + 3 < N) {
-        if (bias) {
-          const float4_t b4 = *reinterpret_cast<const float4_t*>(bias + ncol);
-          v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
-        }
-        if (do_gelu) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
-        }
-        if (res) {
-          const float4_t r4 = *reinterpret_cast<const float4_t*>(res + (size_t)m * ldr + ncol);
-          v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
-        }
-        if (out_f32) {
-          *reinterpret_cast<float4_t*>(reinterpret_cast<float*>(Cv) + (size_t)m * ldc + ncol) =
-              (float4_t){v[0], v[1], v[2], v[3]};
-        } else {
-          uint2 pk;
-          pk.x = pack_bf2(v[0], v[1]);
-          pk.y = pack_bf2(v[2], v[3]);
-          *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(Cv) + (size_t)m * ldc + ncol) = pk;
-        }
-      } else {
-        for (int e = 0; e < 4 && ncol + e < N; ++e) {
-          float x = v[e];
-          if (bias) x += bias[ncol + e];
-          if (do_gelu) x = gelu_erf(x);
-          if (res) x += res[(size_t)m * ldr + ncol + e];
-          if (out_f32) reinterpret_cast<float*>(Cv)[(size_t)m * ldc + ncol + e] = x;
-          else reinterpret_cast<bf16_t*>(Cv)[(size_t)m * ldc + ncol + e] = f2bf(x);
-        }
-      }
-    }
+    const int sw = (lr >> 1) & 7;
+    const unsigned sbase = (unsigned)(uintptr_t)smem;
+    unsigned ra0 = sbase + (wm * 128 + lr) * 128 + ((lg ^ sw) << 4);
+    unsigned ra1 = sbase + (wm * 128 + lr) * 128 + (((4 + lg) ^ sw) << 4);
+    unsigned rb0 = sbase + X4_BREG + (wn * 64 + lr) * 128 + ((lg ^ sw) << 4);
+    unsigned rb1 = sbase + X4_BREG + (wn * 64 + lr) * 128 + (((4 + lg) ^ sw) << 4);
+    int4v_t sa, sb;
+    sa[0] = (int)(unsigned)(uintptr_t)A;
+    sa[1] = (int)((unsigned)((uintptr_t)A >> 32) & 0xffffu);
+    sa[2] = -1;
+    sa[3] = 0x00020000;
+    sb[0] = (int)(unsigned)(uintptr_t)B;
+    sb[1] = (int)((unsigned)((uintptr_t)B >> 32) & 0xffffu);
+    sb[2] = -1;
+    sb[3] = 0x00020000;
+    unsigned koff = (unsigned)kt0 * 128u, cnt = (unsigned)nt, wr = sbase + wave * 1024;
+    X4_DISPATCH8(V);
+  }
+
+  char* ep = smem + wave * 16384;
+  unsigned wa0, wa1, wa2, wa3;
+  {
+    const unsigned b0 = (unsigned)(uintptr_t)ep + lr * 256 + ((lg ^ (lr & 3)) << 4);
+    wa0 = b0 + ((0 ^ (lr >> 2)) << 6);
+    wa1 = b0 + ((1 ^ (lr >> 2)) << 6);
+    wa2 = b0 + ((2 ^ (lr >> 2)) << 6);
+    wa3 = b0 + ((3 ^ (lr >> 2)) << 6);
+  }
+#define X8_WRITE(TXT)                                                                                                        \
+  asm volatile(TXT ::"v"(wa0), "v"(wa1), "v"(wa2), "v"(wa3), "{a[0:31]}"(c[0]), "{a[32:63]}"(c[1]), "{a[64:95]}"(c[2]),      \
+               "{a[96:127]}"(c[3])                                                                                           \
+               : "memory")
+#pragma unroll 1
+  for (int h = 0; h < 2; ++h) {
+    if (h == 0) X8_WRITE(X8_WR_0);
+    else X8_WRITE(X8_WR_1);
+    // SwiGLU: wave (wm, wn) holds gate columns for wn < 2 and pairs with (wm, wn + 2), as in gemm_256.hip
+    x_readout(smem, ep, lane, m0 + wm * 128 + h * 64, wn, n0, wm * 4 + (wn & 1), 2, wn >> 1, wn & 1, Cv, bias, res, M, N, ldc, ldr,
+              flags, alpha, aux, ldaux);
   }
 }
 
@@ -331,7 +428,7 @@ int mh_launch_gemm_x4(const void* A, int lda, const void* B, int ldb, void* C, i
   }
   const int tiles_m = (M + X4_BM - 1) / X4_BM, tiles_n = (N + X4_BN - 1) / X4_BN;
   const size_t shmem = 2 * X4_BUF;   // 128 KiB -> one 4-wave workgroup per CU
-  const dim3 grid(tiles_m * tiles_n, splits), block(256);
+  const dim3 grid(tiles_m * tiles_n, splits);
   if (g_mh_prof_on) mh_prof_pre(stream, 2, M, N, K, splits, flags);
 #define X4_LAUNCH(V)                                                                                                           \
   {                                                                                                                            \
@@ -340,25 +437,22 @@ int mh_launch_gemm_x4(const void* A, int lda, const void* B, int ldb, void* C, i
       (void)hipFuncSetAttribute((const void*)gemm_x4_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);       \
       attr_set = true;                                                                                                         \
     }                                                                                                                          \
-    hipLaunchKernelGGL(gemm_x4_kernel<V>, grid, block, shmem, stream, (const bf16_t*)A, (const bf16_t*)B, C, bias, residual,   \
+    hipLaunchKernelGGL(gemm_x4_kernel<V>, grid, dim3(256), shmem, stream, (const bf16_t*)A, (const bf16_t*)B, C, bias, residual,   \
                        M, N, K, lda, ldb, ldc, ldr, flags, alpha, tiles_m, tps, split_stride, aux, ldaux);                     \
   }
+#define X8_LAUNCH(V)                                                                                                           \
+  {                                                                                                                            \
+    static bool attr_set = false;                                                                                              \
+    if (!attr_set) {                                                                                                           \
+      (void)hipFuncSetAttribute((const void*)gemm_x8_kernel<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);       \
+      attr_set = true;                                                                                                         \
+    }                                                                                                                          \
+    hipLaunchKernelGGL(gemm_x8_kernel<V>, grid, dim3(512), shmem, stream, (const bf16_t*)A, (const bf16_t*)B, C, bias,         \
+                       residual, M, N, K, lda, ldb, ldc, ldr, flags, alpha, tiles_m, tps, split_stride, aux, ldaux);           \
+  }
   switch (x4_variant) {
-#if X4_NVARIANTS > 1
-    case 1: X4_LAUNCH(1) break;
-    case 2: X4_LAUNCH(2) break;
-    case 3: X4_LAUNCH(3) break;
-    case 4: X4_LAUNCH(4) break;
-    case 5: X4_LAUNCH(5) break;
-    case 6: X4_LAUNCH(6) break;
-    case 7: X4_LAUNCH(7) break;
-    case 8: X4_LAUNCH(8) break;
-    case 9: X4_LAUNCH(9) break;
-    case 10: X4_LAUNCH(10) break;
-    case 11: X4_LAUNCH(11) break;
-    case 12: X4_LAUNCH(12) break;
-#endif
-    default: X4_LAUNCH(0) break;
+    X4_LAUNCH_SWITCH
+    default: return MH_ERR_ARG;
   }
   if (g_mh_prof_on) mh_prof_post(stream);
   MH_CHECK_LAUNCH();

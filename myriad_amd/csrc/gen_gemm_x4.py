@@ -38,28 +38,35 @@ BREG = 0x8000     # offset of the B region inside a buffer
 #   fine    1: the loop edge waits only for the fragments the first MFMA row needs (lgkmcnt(7)); row i of the next
 #           iteration waits for its own A fragment with a counted lgkmcnt
 #   ko      timing-only knock-outs (WRONG results): "dma", "rd", "bar", "mfma" in any combination
-DEFAULT = dict(rd=2, dma=3, mid=36, end=96, fine=1, ko="")
+#   waves   4: 2 x 2 waves, 128 x 128 per wave, one wave per SIMD (256 accumulators, 128 MFMA slots per iteration)
+#           8: 2 x 4 waves, 128 x 64 per wave, two waves per SIMD (128 accumulators, 64 MFMA slots per iteration per wave; each
+#              wave issues half the requests: 4 + 4, m0 stride 8192) -- what one wave cannot hide under its own MFMAs (the issue
+#              time of its LDS-DMA requests and fragment reads) the SIMD's other wave fills
+X4 = dict(waves=4, rd=2, dma=3, mid=36, end=96, fine=1, ko="")
+X8 = dict(waves=8, rd=1, dma=3, mid=14, end=50, fine=1, ko="")
+DEFAULT = X8        # shipped: tools/gemm_x4_sweep.py, profiles/r04_gemm_x4.md
 SWEEP = [
-    dict(DEFAULT),
-    dict(DEFAULT, fine=0, end=92, mid=42),
-    dict(DEFAULT, mid=42),
-    dict(DEFAULT, dma=2),
-    dict(DEFAULT, fine=0, end=84, mid=34),
-    dict(DEFAULT, ko="dma"),
-    dict(DEFAULT, ko="rd"),
-    dict(DEFAULT, ko="bar"),
-    dict(DEFAULT, ko="dma rd"),
-    dict(DEFAULT, ko="dma rd bar"),
-    dict(DEFAULT, ko="mfma"),
-    dict(DEFAULT, ko="dma rd bar mfma32"),
-    dict(DEFAULT, ko="mfma32"),
+    dict(X8),
+    dict(X4),
+    dict(X8, mid=18),
+    dict(X8, dma=2),
+    dict(X8, dma=4, end=52),
+    dict(X8, rd=2, mid=24),
+    dict(X8, fine=0),
+    dict(X8, ko="bar"),
+    dict(X8, ko="dma"),
+    dict(X8, ko="rd"),
+    dict(X8, ko="dma rd bar"),
+    dict(X8, ko="mfma"),
 ]
 
-B0, B1, A0, A1 = 0, 32, 64, 96
+# register map per geometry (VGPR numbers): fragment bases of k-half 0 / 1, request offsets, fragment-row LDS addresses
+GEO = {4: dict(B0=0, B1=32, A0=64, A1=96, VA=128, VB=136, RA0=144, RA1=145, RB0=146, RB1=147),
+       8: dict(B0=0, B1=16, A0=32, A1=64, VA=96, VB=100, RA0=104, RA1=105, RB0=106, RB1=107)}   # 108 VGPRs + 128 accumulators: two waves per SIMD
 
 
-def acc(i, j):
-    b = (i * 8 + j) * 4
+def acc(i, j, nj=8):
+    b = (i * nj + j) * 4
     return f"a[{b}:{b + 3}]"
 
 
@@ -67,81 +74,90 @@ def vreg(base, n):
     return f"v[{base + 4 * n}:{base + 4 * n + 3}]"
 
 
-def mfma(i, j, ab, bb):
-    return f"v_mfma_f32_16x16x32_bf16 {acc(i, j)}, {vreg(bb, j)}, {vreg(ab, i)}, {acc(i, j)}"
+def mfma(i, j, ab, bb, nj=8):
+    return f"v_mfma_f32_16x16x32_bf16 {acc(i, j, nj)}, {vreg(bb, j)}, {vreg(ab, i)}, {acc(i, j, nj)}"
 
 
-def reads(half):
-    """16 ds_read_b128 of k-half `half`: B fragments first (the first MFMA row needs all eight), then A."""
+def reads(half, nj=8):
+    """nj + 8 ds_read_b128 of k-half `half`: B fragments first (the first MFMA row needs all of them), then A."""
     out = []
-    bb, ab = (B0, A0) if half == 0 else (B1, A1)
-    va, vb = (144, 146) if half == 0 else (145, 147)
-    for j in range(8):
+    g = GEO[4 if nj == 8 else 8]
+    bb, ab = (g["B0"], g["A0"]) if half == 0 else (g["B1"], g["A1"])
+    va, vb = (g["RA0"], g["RB0"]) if half == 0 else (g["RA1"], g["RB1"])
+    for j in range(nj):
         out.append(f"ds_read_b128 {vreg(bb, j)}, v{vb} offset:{j * 2048}")
     for i in range(8):
         out.append(f"ds_read_b128 {vreg(ab, i)}, v{va} offset:{i * 2048}")
     return out
 
 
-def dma_requests():
-    """16 requests: (m0 setup, load) pairs; m0 walks this wave's slots (stride 4096) in the A then the B region."""
+def dma_requests(waves=4):
+    """The wave's requests of one k-tile: (m0 setup, load) pairs; m0 walks this wave's slots (one 1-KiB slot per `waves`) in the
+    A then the B region.  4 waves: 8 + 8 requests, 8 waves: 4 + 4."""
     out = []
-    for i in range(8):
-        pre = "s_mov_b32 m0, s46" if i == 0 else "s_add_u32 m0, m0, 0x1000"
-        out.append((pre, f"buffer_load_dwordx4 v{128 + i}, s[36:39], s44 offen lds"))
-    for i in range(8):
-        pre = f"s_add_u32 m0, s46, {BREG}" if i == 0 else "s_add_u32 m0, m0, 0x1000"
-        out.append((pre, f"buffer_load_dwordx4 v{136 + i}, s[40:43], s44 offen lds"))
+    n, stride, g = 32 // waves, 1024 * waves, GEO[waves]
+    for i in range(n):
+        pre = "s_mov_b32 m0, s46" if i == 0 else f"s_add_u32 m0, m0, {stride}"
+        out.append((pre, f"buffer_load_dwordx4 v{g['VA'] + i}, s[36:39], s44 offen lds"))
+    for i in range(n):
+        pre = f"s_add_u32 m0, s46, {BREG}" if i == 0 else f"s_add_u32 m0, m0, {stride}"
+        out.append((pre, f"buffer_load_dwordx4 v{g['VB'] + i}, s[40:43], s44 offen lds"))
     return out
 
 
 def body(kind, V):
     """kind: 'steady' (requests k-tile t+2, reads t+1), 'tail2' (no requests, reads t+1), 'last' (neither)."""
     rd, dma, mid, end, fine, ko = V["rd"], V["dma"], V["mid"], V["end"], V["fine"], V["ko"].split()
-    extras = {s: [] for s in range(-1, 128)}                # instructions that ride behind MFMA slot s
+    waves = V["waves"]
+    nj = 8 if waves == 4 else 4                             # B fragments per wave
+    nslot = 8 * nj * 2                                      # MFMA slots per iteration
+    nrd, nreq = 8 + nj, 64 // waves                         # reads per k-half, requests per k-tile (per wave)
+    extras = {s: [] for s in range(-1, nslot)}              # instructions that ride behind MFMA slot s
     if "rd" not in ko:
-        for n, r in enumerate(reads(1)):
+        for n, r in enumerate(reads(1, nj)):
             extras[n * rd].append(r)
-    assert 15 * rd < mid
+    assert (nrd - 1) * rd < mid
     extras[mid].append("s_waitcnt lgkmcnt(0)")              # every wave has read all of cur (also fences the epilogue's LDS use)
     if "bar" not in ko:
         extras[mid].append("s_barrier")
     if fine:
-        # A fragment i of k-half 0 (requested at the end of the previous iteration, after the eight B fragments) is first read by
-        # slot 8 i: LDS operations return in order, so it has landed once at most (7 - i) older-still reads plus the k-half 1
+        # A fragment i of k-half 0 (requested at the end of the previous iteration, after the B fragments) is first read by
+        # slot nj * i: LDS operations return in order, so it has landed once at most (7 - i) older-still reads plus the k-half 1
         # reads issued since (one per `rd` slots) are outstanding.  lgkmcnt saturates at 15: waiting for more is only earlier.
         for i in range(1, 8):
-            issued = min(16, (8 * i - 1) // rd + 1)
-            extras[8 * i - 1].append(f"s_waitcnt lgkmcnt({min(15, 7 - i + issued)})")
+            issued = min(nrd, (nj * i - 1) // rd + 1)
+            extras[nj * i - 1].append(f"s_waitcnt lgkmcnt({min(15, 7 - i + issued)})")
     if kind == "steady" and "dma" not in ko:
         s = mid + 1
-        for pre, ld in dma_requests():
+        for pre, ld in dma_requests(waves):
             extras[s].append(pre)                           # m0 one slot ahead of the request that reads it
             extras[s + 1].append(ld)
             s += dma
         assert s - dma + 1 < end, "all requests must be issued before the END wait"
     # the k-half 1 address registers move to the other buffer once their reads of cur are issued
-    extras[64] += [f"v_xor_b32 v{r}, 0x10000, v{r}" for r in (144, 145, 146, 147)]
+    g = GEO[waves]
+    extras[nslot // 2] += [f"v_xor_b32 v{r}, 0x10000, v{r}" for r in (g["RA0"], g["RA1"], g["RB0"], g["RB1"])]
     if kind != "last":
-        extras[end].append("s_waitcnt vmcnt(16)" if (kind == "steady" and "dma" not in ko) else "s_waitcnt vmcnt(0)")
+        extras[end].append(f"s_waitcnt vmcnt({nreq})" if (kind == "steady" and "dma" not in ko) else "s_waitcnt vmcnt(0)")
         if "bar" not in ko:
             extras[end].append("s_barrier")
         if "rd" not in ko:
-            for n, r in enumerate(reads(0)):
-                extras[end + 1 + n * rd].append(r)
-        assert end + 1 + 15 * rd <= 127
+            step = rd if end + 1 + (nrd - 1) * rd <= nslot - 1 else 1
+            for n, r in enumerate(reads(0, nj)):
+                extras[end + 1 + n * step].append(r)
+            assert end + 1 + (nrd - 1) * step <= nslot - 1
     L = []
     slot = 0
-    for ab, bb in ((A0, B0), (A1, B1)):
+    for ab, bb in ((g["A0"], g["B0"]), (g["A1"], g["B1"])):
         for i in range(8):
-            for j in range(8):
+            for j in range(nj):
                 if "mfma32" in ko:
                     # timing probe: the same FLOPs as 32x32x16 instructions (half as many, twice as long); wrong results
                     if slot % 2 == 0:
                         q = (slot // 2) % 16
                         L.append(f"v_mfma_f32_32x32x16_bf16 a[{q * 16}:{q * 16 + 15}], {vreg(bb, j)}, {vreg(ab, i)}, a[{q * 16}:{q * 16 + 15}]")
                 elif "mfma" not in ko:
-                    L.append(mfma(i, j, ab, bb))
+                    L.append(mfma(i, j, ab, bb, nj))
                 L += extras[slot]
                 slot += 1
     if kind != "last":
@@ -153,28 +169,31 @@ def body(kind, V):
 
 
 def program(V):
+    waves = V["waves"]
+    nj = 8 if waves == 4 else 4
+    nacc = 8 * nj * 4
+    nreq = 64 // waves
     P = ["s_nop 4"]
-    zero = [f"v_accvgpr_write_b32 a{n}, 0" for n in range(256)]
+    zero = [f"v_accvgpr_write_b32 a{n}, 0" for n in range(nacc)]
+    per = nacc // nreq
     # ---- prologue: k-tile 0 -> buffer 0, k-tile 1 -> buffer 1; the accumulators are zeroed in the shadow of the requests' issue
-    for pre, ld in dma_requests():
-        P += [pre, "s_nop 0", ld] + [zero.pop() for _ in range(8)]
+    for pre, ld in dma_requests(waves):
+        P += [pre, "s_nop 0", ld] + [zero.pop() for _ in range(per)]
     P.append("s_add_u32 s44, s44, 128")
     P.append("s_cmp_lt_u32 s45, 2")
     P.append("s_cbranch_scc1 X4_ONE_%=")
     P.append("s_xor_b32 s46, s46, 0x10000")
-    z2 = list(zero)
-    for pre, ld in dma_requests():
-        P += [pre, "s_nop 0", ld] + [z2.pop() for _ in range(8)]
+    for pre, ld in dma_requests(waves):
+        P += [pre, "s_nop 0", ld]
     P.append("s_add_u32 s44, s44, 128")
     P.append("s_xor_b32 s46, s46, 0x10000")
-    P.append("s_waitcnt vmcnt(16)")
+    P.append(f"s_waitcnt vmcnt({nreq})")
     P.append("s_branch X4_GO_%=")
     P.append("X4_ONE_%=:")
-    P += zero
     P.append("s_waitcnt vmcnt(0)")
     P.append("X4_GO_%=:")
     P.append("s_barrier")
-    P += reads(0)
+    P += reads(0, nj)
     P.append("s_waitcnt lgkmcnt(0)")
     # ---- loop
     P.append("X4_LOOP_%=:")
@@ -195,6 +214,11 @@ def program(V):
     return P
 
 
+def block_writer8(h):
+    """8-wave form, epilogue block h (64 of the wave's 128 rows x its 64 columns): accumulators (i = h*4 + ii, j) -> slice."""
+    return [f"ds_write_b128 %{jj}, {acc(h * 4 + ii, jj, 4)} offset:{ii * 4096}" for ii in range(4) for jj in range(4)]
+
+
 def block_writer(blk):
     """Epilogue block blk = cb * 2 + h: accumulators (i = h*4 + ii, j = cb*4 + jj) -> the wave's LDS slice, straight from the
     AGPRs; %0..%3 = the lane's slice address for jj = 0..3 (the row's chunk swizzle is in it), ii * 16 rows in the offset."""
@@ -210,15 +234,27 @@ def main():
         f.write(f"#define X4_NVARIANTS {len(variants)}\n")
         for vi, V in enumerate(variants):
             lines = program(V)
-            f.write(f"// variant {vi}: {V}\n#define X4_LOOP_{vi} \\\n")
+            f.write(f"// variant {vi}: {V}\n#define X4_WAVES_{vi} {V['waves']}\n#define X4_LOOP_{vi} \\\n")
             for ln in lines:
                 f.write('  "' + ln + '\\n\\t" \\\n')
             f.write('  ""\n')
             n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
+            if vi == len(variants) - 1:
+                for w, asm in ((4, "X4_ASM"), (8, "X8_ASM")):
+                    idx = [i for i, v in enumerate(variants) if v["waves"] == w]
+                    chain = " else ".join(f"if constexpr (V == {i}) {{ {asm}(X4_LOOP_{i}); }}" for i in idx) or "(void)0"
+                    f.write(f"#define X4_DISPATCH{w}(V) {chain}\n")
+                cases = " ".join(f"case {i}: X{v['waves']}_LAUNCH({i}) break;" for i, v in enumerate(variants))
+                f.write(f"#define X4_LAUNCH_SWITCH {cases}\n")
             if vi == 0:
                 for blk in range(4):
                     f.write(f"#define X4_WR_{blk} \\\n")
                     for ln in block_writer(blk):
+                        f.write('  "' + ln + '\\n\\t" \\\n')
+                    f.write('  ""\n')
+                for h in range(2):
+                    f.write(f"#define X8_WR_{h} \\\n")
+                    for ln in block_writer8(h):
                         f.write('  "' + ln + '\\n\\t" \\\n')
                     f.write('  ""\n')
             print(f"variant {vi}: {len(lines)} instructions, {n_mfma} MFMAs  {V}")

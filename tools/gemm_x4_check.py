@@ -9,6 +9,8 @@ L = _lib.load()
 dev = torch.device("cuda:0")
 ops.ensure_workspace(dev)
 quick = "--quick" in sys.argv
+variant = int(sys.argv[sys.argv.index("--variant") + 1]) if "--variant" in sys.argv else 0   # sweep builds only
+L.mhdbg_set_gemm_x4_variant(variant)
 # (M, N, K, out_f32, bias, residual)
 SHAPES = [(256, 256, 64, 0, 0, 0), (256, 256, 128, 0, 0, 0), (256, 256, 192, 1, 0, 0), (300, 1000, 256, 0, 1, 0), (1184, 4160, 1024, 1, 1, 1),
           (1184, 12288, 4160, 0, 0, 0), (1184, 22016, 4096, 0, 0, 0), (1184, 11008, 4096, 0, 0, 0), (1184, 4096, 22016, 0, 0, 0),

@@ -297,13 +297,14 @@ int mh_patch_label(const void* dest, const void* out, const void* union_mask, vo
    mh_patch_poisson_u8: gradient-domain cloning of patch [hp][wp][3] into out[image] in place.  pms [hp][wp] the clone mask
    (border cleared), eroded [h][w] its ROI after erode(3x3) x 3, ROI h x w at (y0s, x0s) of the patch and (dy0, dx0) of the
    image; Sh [h-2][h-2], Sw [w-2][w-2] sine matrices, cy / cx their 2 cos terms (f64); ws mh_patch_poisson_ws_doubles(h, w)
-   doubles.  float64 throughout, interior = floor(clamp(u, 0, 255) + 1e-6). */
+   doubles.  float64 throughout, interior = floor(clamp(u, 0, 255) + 1e-6).  mixed = 0: cv2.NORMAL_CLONE; 1: cv2.MIXED_CLONE
+   (self_sup_tasks.py:22,47,267: the patch's gradient pair is kept where |Px - Py| > |Dx - Dy|, else the destination's). */
 int mh_patch_resize_u8(const void* src, int image, int H, int W, int sy, int sx, int sh, int sw, const int* xi, const int* xw,
                        const int* yi, const int* yw, void* out, int h, int w, mh_stream_t s);
 long mh_patch_poisson_ws_doubles(int h, int w);
 int mh_patch_poisson_u8(void* out, int image, int H, int W, const void* patch, int hp, int wp, const void* pms,
                         const void* eroded, int y0s, int x0s, int dy0, int dx0, int h, int w, const double* Sh, const double* cy,
-                        const double* Sw, const double* cx, double* ws, mh_stream_t s);
+                        const double* Sw, const double* cx, double* ws, int mixed, mh_stream_t s);
 
 /* Gated AdamW: torch.optim.AdamW skips parameters whose .grad is None -- a module no rank used this step (random prompt
    stage, myriad.py:378; DDP find_unused_parameters, runner_base.py:96-98) keeps its parameters, moments and step count.

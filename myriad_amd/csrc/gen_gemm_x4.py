@@ -43,14 +43,15 @@ BREG = 0x8000     # offset of the B region inside a buffer
 #              wave issues half the requests: 4 + 4, m0 stride 8192) -- what one wave cannot hide under its own MFMAs (the issue
 #              time of its LDS-DMA requests and fragment reads) the SIMD's other wave fills
 X4 = dict(waves=4, rd=2, dma=3, mid=36, end=96, fine=1, ko="")
-X8 = dict(waves=8, rd=1, dma=3, mid=14, end=50, fine=1, ko="")
+X8 = dict(waves=8, rd=1, dma=4, mid=14, end=50, fine=1, ko="")
 DEFAULT = X8        # shipped: tools/gemm_x4_sweep.py, profiles/r04_gemm_x4.md
 SWEEP = [
     dict(X8),
     dict(X4),
     dict(X8, mid=18),
     dict(X8, dma=2),
-    dict(X8, dma=4, end=52),
+    dict(X8, dma=4),
+    dict(X8, mid=12),
     dict(X8, rd=2, mid=24),
     dict(X8, fine=0),
     dict(X8, ko="bar"),

@@ -217,11 +217,12 @@ extern "C" int mh_patch_resize_u8(const void* src, int image, int H, int W, int 
 //   non-zero mask; myriad_amd/self_sup.clone_roi).  D = destination ROI, P = the patch where the mask is set (0 elsewhere),
 //   e = the mask eroded 3 x (host), m = e / 255.
 //   rhs(y, x) = div( (1 - m) grad D + m grad P ) - Laplacian(boundary ring of D)         on the (h-2) x (w-2) interior
+//   (mixed != 0, cv2.MIXED_CLONE: grad P is replaced element-wise by grad D where |Px - Py| <= |Dx - Dy|)
 //   u = DST^-1( DST(rhs) / (2 cos(pi (i+1)/(w-1)) + 2 cos(pi (j+1)/(h-1)) - 4) )         (Cloning::solve, as dense sine products)
 //   out = floor(clamp(u, 0, 255) + 1e-6) on the interior; the ring keeps the destination's pixels.
 __global__ void poisson_rhs_kernel(const unsigned char* __restrict__ img, int H, int W, int image, const unsigned char* __restrict__ patch,
                                    int wp, const unsigned char* __restrict__ pms, const unsigned char* __restrict__ er, int y0s,
-                                   int x0s, int dy0, int dx0, int h, int w, double* __restrict__ rhs) {
+                                   int x0s, int dy0, int dx0, int h, int w, double* __restrict__ rhs, int mixed) {
   const int nh = h - 2, nw = w - 2;
   const long n = (long)nh * nw;
   const unsigned char* D0 = img + ((long)image * H + dy0) * W * 3 + (long)dx0 * 3;
@@ -236,8 +237,24 @@ __global__ void poisson_rhs_kernel(const unsigned char* __restrict__ img, int H,
         const long q = (long)(y0s + yy) * wp + (x0s + xx);
         return pms[q] ? (double)patch[q * 3 + c] : 0.0;
       };
-      auto gx = [&](int yy, int xx) { return (Dv(yy, xx + 1) - Dv(yy, xx)) * miv(yy, xx) + (Pv(yy, xx + 1) - Pv(yy, xx)) * mfv(yy, xx); };
-      auto gy = [&](int yy, int xx) { return (Dv(yy + 1, xx) - Dv(yy, xx)) * miv(yy, xx) + (Pv(yy + 1, xx) - Pv(yy, xx)) * mfv(yy, xx); };
+      // MIXED_CLONE (Cloning::mixedClone): the patch's gradient pair at an element is kept where |Px - Py| > |Dx - Dy|, else the
+      // destination's pair stands in for it (both components switch together)
+      auto keep = [&](int yy, int xx) {
+        if (!mixed) return true;
+        const double px = Pv(yy, xx + 1) - Pv(yy, xx), py = Pv(yy + 1, xx) - Pv(yy, xx);
+        const double dx = Dv(yy, xx + 1) - Dv(yy, xx), dy = Dv(yy + 1, xx) - Dv(yy, xx);
+        return fabs(px - py) > fabs(dx - dy);
+      };
+      auto gx = [&](int yy, int xx) {
+        const double d = Dv(yy, xx + 1) - Dv(yy, xx);
+        const double pg = keep(yy, xx) ? Pv(yy, xx + 1) - Pv(yy, xx) : d;
+        return d * miv(yy, xx) + pg * mfv(yy, xx);
+      };
+      auto gy = [&](int yy, int xx) {
+        const double d = Dv(yy + 1, xx) - Dv(yy, xx);
+        const double pg = keep(yy, xx) ? Pv(yy + 1, xx) - Pv(yy, xx) : d;
+        return d * miv(yy, xx) + pg * mfv(yy, xx);
+      };
       const double lap = (gx(y, x) - gx(y, x - 1)) + (gy(y, x) - gy(y - 1, x));
       double ring = 0.0;                                           // 4-neighbour Laplacian of the ROI's boundary ring
       if (x - 1 == 0) ring += Dv(y, 0);
@@ -297,7 +314,8 @@ extern "C" long mh_patch_poisson_ws_doubles(int h, int w) { return h < 3 || w < 
 // 2 cos terms (nh = h - 2, nw = w - 2; myriad_amd/self_sup.dst_tables), ws: mh_patch_poisson_ws_doubles(h, w) doubles.
 extern "C" int mh_patch_poisson_u8(void* out, int image, int H, int W, const void* patch, int hp, int wp, const void* pms,
                                    const void* eroded, int y0s, int x0s, int dy0, int dx0, int h, int w, const double* Sh,
-                                   const double* cy, const double* Sw, const double* cx, double* ws, hipStream_t stream) {
+                                   const double* cy, const double* Sw, const double* cx, double* ws, int mixed,
+                                   hipStream_t stream) {
   if (h < 3 || w < 3) return MH_OK;
   if (!out || !patch || !pms || !eroded || !Sh || !cy || !Sw || !cx || !ws) return MH_ERR_ARG;
   if (y0s < 0 || x0s < 0 || y0s + h > hp || x0s + w > wp || dy0 < 0 || dx0 < 0 || dy0 + h > H || dx0 + w > W) return MH_ERR_ARG;
@@ -307,7 +325,7 @@ extern "C" int mh_patch_poisson_u8(void* out, int image, int H, int W, const voi
   double* t = ws + 3 * n;
   hipLaunchKernelGGL(poisson_rhs_kernel, dim3(ss_grid(n)), dim3(256), 0, stream, (const unsigned char*)out, H, W, image,
                      (const unsigned char*)patch, wp, (const unsigned char*)pms, (const unsigned char*)eroded, y0s, x0s, dy0, dx0, h,
-                     w, r);
+                     w, r, mixed);
   const dim3 grid((nw + 15) / 16, (nh + 15) / 16, 3), block(256);
   // t = Sh . r ;  r = (t . Sw) / (cy[j] + cx[i] - 4) ;  t = Sh . r ;  r = (t . Sw) * 4 / ((nh + 1)(nw + 1))
   hipLaunchKernelGGL(dmatmul_kernel, grid, block, 0, stream, Sh, nh, 0L, r, nw, n, t, nw, n, nh, nw, nh, nullptr, nullptr, 0.0, 1.0);

@@ -277,6 +277,7 @@ class MyriadHIP(nn.Module):
         self._anchor = torch.zeros((), device=self._dev, requires_grad=True)
         self._ctx = None
         self._has_grads, self._bwd_gscale, self._bwd_prev = False, 1.0, None
+        self._accum_count = 0                                  # train_step calls since the last optimiser update (accum_grad_iters)
         self._bridge_used = set()
 
     # ------------------------------------------------------------------ nn.Module plumbing
@@ -738,12 +739,19 @@ class MyriadHIP(nn.Module):
         return out
 
     def train_step(self, samples, lr: float, weight_decay: float = 0.05, allreduce=None, world: int = 1, dp=None,
-                   overlap: bool = True, next_samples=None):
+                   overlap: bool = True, next_samples=None, accum_grad_iters: int = 1):
         """forward + backward (+ gradient all-reduce) + fused AdamW: one optimisation step of
         `BaseTask._train_inner_loop` (base_task.py:233-271) without the autograd bridge.
         With a `DataParallel` (`dp`) and overlap=True the all-reduce + AdamW of step t are hidden behind the frozen
         ViT forward of step t+1 (95 % of the gradient bytes only exist after the whole LLaMA backward, so
-        overlapping with backward hides nothing); call `finish_update()` after the last step."""
+        overlapping with backward hides nothing); call `finish_update()` after the last step.
+
+        accum_grad_iters > 1 (base_task.py:262-271, runner_base.py:311-312): the gradients -- and the per-module use flags -- of
+        that many consecutive calls are summed in the flat buffer (no division, as the reference); the exchange and the AdamW
+        run on the last call of a window, with that call's lr.  A module is skipped by the gated AdamW only if no call of the
+        window (on any rank) used it, which is what `optimizer.zero_grad()` (set_to_none) + DDP leave torch's AdamW.  The
+        reference all-reduces every backward; one exchange of the window's sum is the same gradient.  A window left open at
+        the end of an epoch carries into the next one, as the reference's un-zeroed .grad does."""
         with torch.no_grad():
             vit_out = self._take_prefetched_vit(samples)
             if next_samples is not None:
@@ -756,7 +764,11 @@ class MyriadHIP(nn.Module):
                 vit_out = self.visual_encoder.forward(self._image_of(samples))
                 self.finish_update()
             loss = self._forward_impl(samples, True, vit_out=vit_out)
-            self.backward()
+            self.backward(accumulate=self._accum_count > 0)
+            self._accum_count += 1
+            if self._accum_count < max(int(accum_grad_iters), 1):
+                return loss                                   # inside an accumulation window: no exchange, no update
+            self._accum_count = 0
             if dp is not None and dp.world > 1 and overlap:
                 dp.start(self.store.flat_g_comm, self.store.total)   # RCCL exchange on the side HIP stream (grads + use flags)
                 self._pending_update = (dp, lr, weight_decay)

@@ -453,10 +453,7 @@ class RunnerBase:
         self.log_freq = int(run.get("log_freq", 50))
         self.resume_ckpt_path = run.get("resume_ckpt_path", None)
         self.evaluate_only = bool(run.get("evaluate", False))
-        self.accum_grad_iters = int(run.get("accum_grad_iters", 1))
-        if self.accum_grad_iters != 1:
-            raise NotImplementedError("accum_grad_iters > 1: use model(samples)['loss'].backward() with your own optimiser "
-                                      "(the autograd bridge accumulates); the fused train_step path steps every iteration")
+        self.accum_grad_iters = max(int(run.get("accum_grad_iters", 1)), 1)      # base_task.py:262-271: step every n-th iteration
         out_root = run.get("output_dir", "output")
         self.output_dir = os.path.join(out_root, job_id)
         if self.rank == 0:
@@ -533,7 +530,8 @@ class RunnerBase:
             samples.update({"epoch": epoch, "num_iters_per_epoch": iters, "iters": i})      # base_task.py:217-223
             lr = sched.step(cur_epoch=epoch, cur_step=i)                                    # stepped BEFORE the forward (:229)
             nxt = next(loader) if i + 1 < iters else None                                   # one batch of lookahead: its frozen
-            loss = model.train_step(samples, lr, wd, dp=self.dp, next_samples=nxt)          # ViT forward runs on a side stream
+            loss = model.train_step(samples, lr, wd, dp=self.dp, next_samples=nxt,          # ViT forward runs on a side stream
+                                    accum_grad_iters=self.accum_grad_iters)
             pending.append(loss)                          # the reference reads loss.item() every step (:276), which stalls the
             meters["lr"].update(lr)                       # launch thread behind the GPU; here the values are fetched at log points
             if i % self.log_freq == 0 or i == iters - 1:

@@ -27,6 +27,7 @@ from typing import List, Optional, Sequence, Tuple
 import numpy as np
 
 NORMAL_CLONE = 1                      # cv2.NORMAL_CLONE
+MIXED_CLONE = 2                       # cv2.MIXED_CLONE
 TRUNC_EPS = 1e-6
 # the training split's base arguments (anomaly_detection.py:118-141): MVTec-style and VisA
 NSA_ARGS = dict(num_patches=2, min_object_pct=0, min_overlap_pct=0.25, gamma_params=(2, 0.05, 0.03), resize=True, shift=True,
@@ -153,8 +154,10 @@ def dst_tables(n: int):
     return np.sin(np.pi * np.outer(k, k) / (n + 1)), 2.0 * np.cos(np.pi * k / (n + 1))
 
 
-def poisson_clone_numpy(out: np.ndarray, patch: np.ndarray, pms: np.ndarray, roi) -> None:
-    """Cloning::normalClone (NORMAL_CLONE) on `out` in place, float64, the transform through scipy's DST-I."""
+def poisson_clone_numpy(out: np.ndarray, patch: np.ndarray, pms: np.ndarray, roi, mixed: bool = False) -> None:
+    """Cloning::normalClone (NORMAL_CLONE) -- or, with `mixed`, Cloning::mixedClone (MIXED_CLONE: per element the patch's
+    gradient pair is kept where |Px - Py| > |Dx - Dy|, else the destination's pair, seamless_cloning_impl.cpp) -- on `out` in
+    place, float64, the transform through scipy's DST-I."""
     import scipy.fft as sfft
     y0, x0, dy0, dx0, h, w = roi
     if h < 3 or w < 3:
@@ -164,8 +167,15 @@ def poisson_clone_numpy(out: np.ndarray, patch: np.ndarray, pms: np.ndarray, roi
     P = np.where(m[y0:y0 + h, x0:x0 + w, None] != 0, patch[y0:y0 + h, x0:x0 + w], 0).astype(np.float64)
     me = eroded_mask(pms, roi).astype(np.float64)[..., None]
     mf, mi = me / 255.0, (255.0 - me) / 255.0
-    gx = (D[:, 1:] - D[:, :-1]) * mi[:, :-1] + (P[:, 1:] - P[:, :-1]) * mf[:, :-1]          # forward differences, columns 0..w-2
-    gy = (D[1:] - D[:-1]) * mi[:-1] + (P[1:] - P[:-1]) * mf[:-1]
+    dgx, pgx = D[:, 1:] - D[:, :-1], P[:, 1:] - P[:, :-1]                                    # forward differences, columns 0..w-2
+    dgy, pgy = D[1:] - D[:-1], P[1:] - P[:-1]                                                # rows 0..h-2
+    if mixed:                                                                                # defined where both components are: [h-1, w-1]
+        keep = np.abs(pgx[:-1] - pgy[:, :-1]) > np.abs(dgx[:-1] - dgy[:, :-1])
+        pgx, pgy = pgx.copy(), pgy.copy()
+        pgx[:-1] = np.where(keep, pgx[:-1], dgx[:-1])
+        pgy[:, :-1] = np.where(keep, pgy[:, :-1], dgy[:, :-1])
+    gx = dgx * mi[:, :-1] + pgx * mf[:, :-1]
+    gy = dgy * mi[:-1] + pgy * mf[:-1]
     lap = (gx[1:-1, 1:] - gx[1:-1, :-1]) + (gy[1:, 1:-1] - gy[:-1, 1:-1])                    # interior (h-2) x (w-2)
     ring = D.copy()
     ring[1:-1, 1:-1] = 0
@@ -197,12 +207,18 @@ def _object_masks(ima_dest, ima_src, skip_background):
     return so, do
 
 
-def _mode(mode):
+def _mode(mode, rng=np.random):
+    """self_sup_tasks.py:22,47-48: 'mix' flips a coin between the two Poisson modes -- one np.random.randint(2) draw, the FIRST
+    draw of patch_ex."""
+    if mode == "mix":
+        mode = (NORMAL_CLONE, MIXED_CLONE)[int(rng.randint(2))]
     if mode in (NORMAL_CLONE, "normal_clone", "poisson"):
         return "normal_clone"
+    if mode in (MIXED_CLONE, "mixed_clone"):
+        return "mixed_clone"
     if mode in ("swap", "uniform"):
         return mode
-    raise NotImplementedError(f"blend mode {mode!r}: MIXED_CLONE / 'mix' are not built (no shipped recipe selects them)")
+    raise ValueError("mode not supported" + str(mode))          # self_sup_tasks.py:290-291
 
 
 def plan(ima_dest: np.ndarray, ima_src: Optional[np.ndarray] = None, same: bool = False, num_patches: int = 1, mode="swap",
@@ -211,7 +227,7 @@ def plan(ima_dest: np.ndarray, ima_src: Optional[np.ndarray] = None, same: bool 
          cutpaste_patch_generation: bool = False, resize_bounds=(0.7, 1.3), rng=np.random) -> Tuple[List[PatchOp], float]:
     """The random part of `patch_ex` (self_sup_tasks.py:44-95, 116-256, 271-279): which patches go where.  `rng` is np.random
     (the reference's generator) or a RandomState.  Returns (operations in application order, interpolation factor)."""
-    mode = _mode(mode)
+    mode = _mode(mode, rng)
     if cutpaste_patch_generation:
         width_bounds_pct, resize, skip_background = None, False, None
         min_overlap_pct = min_object_pct = gamma_params = None
@@ -312,7 +328,7 @@ def _plan_one(Hh, Ww, so, do, shift, width_bounds_pct, gamma_params, min_object_
     if skip_bg:
         pm = pm & (so_p | do[a1:b1, a2:b2])
     pms = roi = None
-    if mode == "normal_clone":                            # :271-279
+    if mode in ("normal_clone", "mixed_clone"):          # :267-279
         int_factor = np.uint8(np.ceil(factor * 255))
         pms = int_factor * (pm | ((1 - so_p) & (1 - do[a1:b1, a2:b2]))) if skip_bg else int_factor * pm
         pms[0], pms[-1], pms[:, 0], pms[:, -1] = 0, 0, 0, 0
@@ -341,8 +357,8 @@ def apply_numpy(ima_dest: np.ndarray, ima_src: np.ndarray, ops: Sequence[PatchOp
         src = ima_src[sy:sy + op.src_size[0], sx:sx + op.src_size[1]]
         if op.resized:
             src = resize_linear_u8(src, (w, h))
-        if op.mode == "normal_clone":
-            poisson_clone_numpy(out, src, op.pms, op.roi)
+        if op.mode in ("normal_clone", "mixed_clone"):
+            poisson_clone_numpy(out, src, op.pms, op.roi, mixed=op.mode == "mixed_clone")
         elif op.mode == "swap":
             out[y0:y0 + h, x0:x0 + w] = np.where(pm.astype(bool), src, out[y0:y0 + h, x0:x0 + w])
         else:
@@ -414,8 +430,9 @@ class PatchExHIP:
         for b, (ops_b, _f) in enumerate(plans):
             for op in ops_b:
                 (sy, sx), (y0, x0, h, w) = op.src_box, op.dst_box
-                pooled = op.resized or op.mode == "normal_clone"
-                mode = {"swap": 0, "uniform": 1, "normal_clone": 2}[op.mode] | (4 if pooled and op.mode != "normal_clone" else 0)
+                clone = op.mode in ("normal_clone", "mixed_clone")
+                pooled = op.resized or clone
+                mode = {"swap": 0, "uniform": 1, "normal_clone": 2, "mixed_clone": 2}[op.mode] | (4 if pooled and not clone else 0)
                 recs.append(struct.pack("<8iqdq", b, y0, x0, h, w, sy, sx, mode, off, float(op.factor), poff))
                 masks.append(np.ascontiguousarray(op.mask, dtype=np.uint8).reshape(-1))
                 t = None
@@ -442,7 +459,7 @@ class PatchExHIP:
                     _lib.check(self.lib.mh_patch_resize_u8(src_u8.data_ptr(), b, H, W, sy, sx, op.src_size[0], op.src_size[1],
                                                            tp + 4 * t[0], tp + 4 * t[1], tp + 4 * t[2], tp + 4 * t[3],
                                                            patches.data_ptr() + p_off, h, w, O._s()), "mh_patch_resize_u8")
-                if op.mode == "normal_clone":
+                if op.mode in ("normal_clone", "mixed_clone"):
                     y0s, x0s, dy0, dx0, rh, rw = op.roi
                     if rh >= 3 and rw >= 3:
                         pms = torch.from_numpy(np.ascontiguousarray(op.pms, dtype=np.uint8)).to(self.dev)
@@ -453,7 +470,8 @@ class PatchExHIP:
                         keep += [pms, er, ws]
                         _lib.check(self.lib.mh_patch_poisson_u8(out.data_ptr(), b, H, W, patches.data_ptr() + p_off, h, w,
                                                                 pms.data_ptr(), er.data_ptr(), y0s, x0s, dy0, dx0, rh, rw, Sh.data_ptr(),
-                                                                cy.data_ptr(), Sw.data_ptr(), cx.data_ptr(), ws.data_ptr(), O._s()),
+                                                                cy.data_ptr(), Sw.data_ptr(), cx.data_ptr(), ws.data_ptr(),
+                                                                1 if op.mode == "mixed_clone" else 0, O._s()),
                                    "mh_patch_poisson_u8")
                 _lib.check(self.lib.mh_patch_blend_u8(out.data_ptr(), src_u8.data_ptr(), pool.data_ptr(), ops_dev.data_ptr() + 56 * o,
                                                       ctypes.cast(one(h), ctypes.c_void_p), ctypes.cast(one(w), ctypes.c_void_p), 1, B, H,

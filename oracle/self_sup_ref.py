@@ -35,11 +35,16 @@ def patch_ex(ima_dest, ima_src=None, same=False, num_patches=1, mode="swap", wid
              resize=False, gamma_params=None, intensity_logistic_params=(1 / 6, 20), resize_bounds=(0.7, 1.3),
              num_ellipses=None, cutpaste_patch_generation=False):
     """self_sup_tasks.py:11-113.  Returns (patchex uint8, label, label_boxes).  mode: 'swap', 'uniform', or
-    NORMAL_CLONE (= cv2.NORMAL_CLONE = 1, also spelled 'normal_clone')."""
+    NORMAL_CLONE (= cv2.NORMAL_CLONE = 1, also spelled 'normal_clone'), MIXED_CLONE (= 2, 'mixed_clone'), or 'mix' (a coin flip
+    between the two Poisson modes, :47-48: the first random draw of the call)."""
+    if mode == "mix":
+        mode = (NORMAL_CLONE, MIXED_CLONE)[np.random.randint(2)]
     if mode == "normal_clone":
         mode = NORMAL_CLONE
-    if mode not in ("swap", "uniform", NORMAL_CLONE):
-        raise NotImplementedError("MIXED_CLONE / 'mix' are not restated (no shipped recipe selects them)")
+    if mode == "mixed_clone":
+        mode = MIXED_CLONE
+    if mode not in ("swap", "uniform", NORMAL_CLONE, MIXED_CLONE):
+        raise ValueError("mode not supported" + str(mode))          # :290-291
     if cutpaste_patch_generation:                                   # :47-54
         width_bounds_pct, resize, skip_background = None, False, None
         min_overlap_pct = min_object_pct = gamma_params = None
@@ -186,7 +191,7 @@ def _patch_ex(ima_dest, ima_src, dest_obj, src_obj, mode, shift, width_bounds_pc
                 return ima_dest.copy(), ((0, 0), (0, 0)), None
     if skip_bg:                                                     # :255-256
         pm = pm & (so | dest_obj[a1:b1, a2:b2])
-    if mode == NORMAL_CLONE:                                        # :269-288 Poisson interpolation
+    if mode in (NORMAL_CLONE, MIXED_CLONE):                         # :267-288 Poisson interpolation
         int_factor = np.uint8(np.ceil(factor * 255))
         if skip_bg:                                                 # background added to the mask to avoid artefacts
             pms = int_factor * (pm | ((1 - so) & (1 - dest_obj[a1:b1, a2:b2])))
@@ -197,7 +202,7 @@ def _patch_ex(ima_dest, ima_src, dest_obj, src_obj, mode, shift, width_bounds_pc
         if np.sum(pms > 0) < 50:
             return ima_dest.copy(), ((0, 0), (0, 0)), None
         try:
-            out = seamless_clone(src, ima_dest, pms, center, NORMAL_CLONE)
+            out = seamless_clone(src, ima_dest, pms, center, mode)
         except ValueError:                                          # cv2.error in the reference
             return ima_dest.copy(), ((0, 0), (0, 0)), None
     elif mode == "swap":                                            # :258-262 (uint8 arithmetic, wraps like numpy's)
@@ -289,8 +294,8 @@ def seamless_clone(src: np.ndarray, dst: np.ndarray, mask: np.ndarray, center, f
     size around `center`; seamless_cloning_impl.cpp (normalClone): forward-difference gradients of the destination ROI and
     of the masked source ROI, mixed with the mask eroded 3 x (3 x 3, border never erodes), divergence, minus the Laplacian
     of the ROI's boundary ring, Poisson solve with that ring as Dirichlet data, clamp to [0, 255] and truncate."""
-    if flags != NORMAL_CLONE:
-        raise NotImplementedError("only NORMAL_CLONE (the shipped recipe) is restated")
+    if flags not in (NORMAL_CLONE, MIXED_CLONE):
+        raise NotImplementedError("only NORMAL_CLONE (the shipped recipe) and MIXED_CLONE are restated")
     m = np.array(mask, copy=True)
     if m.ndim == 3:
         m = m[..., 0]
@@ -328,8 +333,15 @@ def seamless_clone(src: np.ndarray, dst: np.ndarray, mask: np.ndarray, center, f
         g[-1] = a[-2] - a[-1]
         return g
 
-    gx = grad_x(D) * mi + grad_x(P) * mf
-    gy = grad_y(D) * mi + grad_y(P) * mf
+    pgx, pgy, dgx, dgy = grad_x(P), grad_y(P), grad_x(D), grad_y(D)
+    if flags == MIXED_CLONE:
+        # Cloning::mixedClone (seamless_cloning_impl.cpp): per element the patch's gradient pair is kept where
+        # |Px - Py| > |Dx - Dy| (OpenCV compares the DIFFERENCE of the two components, not their magnitude), else the
+        # destination's pair takes its place -- both then weighted by the eroded mask like the patch gradients of normalClone
+        keep = np.abs(pgx - pgy) > np.abs(dgx - dgy)
+        pgx, pgy = np.where(keep, pgx, dgx), np.where(keep, pgy, dgy)
+    gx = dgx * mi + pgx * mf
+    gy = dgy * mi + pgy * mf
     lap = np.zeros_like(D)                                            # filter2D [-1, 1, 0]: g(x) - g(x-1), interior only is used
     lap[:, 1:] += gx[:, 1:] - gx[:, :-1]
     lap[1:, :] += gy[1:, :] - gy[:-1, :]

@@ -76,3 +76,38 @@ def test_two_ranks_on_one_gpu_equal_one_process_summing_their_gradients(mode, tm
     # and the parameters did move
     model0, _ = C.build_model(torch.device("cuda:0"))
     assert (model0.store.flat_p.cpu() - s0["p"]).abs().max().item() > 1e-5
+
+
+def test_accum_grad_iters_sums_the_window_and_steps_once():
+    """base_task.py:262-271: with accum_grad_iters = 2 the optimiser steps on every second iteration with the SUM of the two
+    backward passes (no division) and that iteration's lr; a module used by only one call of the window is updated, one used
+    by none keeps its weights, moments and step count.  train_step(..., accum_grad_iters=2) twice == one AdamW on g1 + g2."""
+    from tests import dp_common as C
+    dev = torch.device("cuda:0")
+    stages = [2, 1, 0, 0]                                     # window 1: VETokenizer used by the 2nd call only; window 2: VEInstructor by none
+    got, cfg = C.build_model(dev)
+    got.lora.base_seed = 7
+    for i in range(4):
+        got.fixed_stage = stages[i]
+        got.train_step(C.batch(0, i, cfg["vocab"], dev), C.LRS[i % 3], 0.05, accum_grad_iters=2)
+    got.finish_update()
+    ref, _ = C.build_model(dev)
+    ref.lora.base_seed = 7
+    st = ref.store
+    for w in range(2):
+        gsum = None
+        for j in range(2):
+            i = 2 * w + j
+            ref.fixed_stage = stages[i]
+            with torch.no_grad():
+                ref._forward_impl(C.batch(0, i, cfg["vocab"], dev), True)
+                ref.backward()
+            torch.cuda.synchronize()
+            g = st.flat_g_comm.clone()
+            gsum = g if gsum is None else g + gsum
+        st.flat_g_comm.copy_(gsum)
+        st.adamw_step(C.LRS[(2 * w + 1) % 3], 0.05)
+    a, b = C.snapshot(got), C.snapshot(ref)
+    for k in ("p", "m", "v"):
+        assert torch.equal(a[k], b[k]), k
+    assert a["steps"] == b["steps"] and a["steps"]["VETokenizer"] == 2 and a["steps"]["VEInstructor"] == 1

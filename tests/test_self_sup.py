@@ -41,8 +41,8 @@ def test_product_host_path_matches_the_oracle(name, seed, kw):
     assert np.array_equal(patchex, G[name + "_patchex"])
     assert np.array_equal(np.asarray(boxes, np.int64).reshape(-1, 4), G[name + "_boxes"])
     np.testing.assert_allclose(np.asarray(label, np.float64), G[name + "_label"], rtol=0, atol=1e-12)
-    with pytest.raises(NotImplementedError):
-        P.patch_ex(dest, src, mode="mix")
+    with pytest.raises(ValueError):
+        P.patch_ex(dest, src, mode="no_such_mode")               # self_sup_tasks.py:290-291
 
 
 @pytest.mark.gpu
@@ -127,6 +127,20 @@ def test_poisson_clone_properties():
     pms = mask.copy(); pms[0] = pms[-1] = 0; pms[:, 0] = pms[:, -1] = 0
     P.poisson_clone_numpy(out2, src, pms, P.clone_roi(pms, (70, 50), dst.shape[:2]))
     assert np.array_equal(out2, out)
+    # MIXED_CLONE (Cloning::mixedClone, restated): (6) a flat source has no gradients, so the destination's own gradients win
+    # everywhere and nothing changes -- where NORMAL_CLONE flattens the region; (7) a source whose texture dominates
+    # (|Px - Py| > |Dx - Dy| everywhere) gives exactly the NORMAL_CLONE result; (8) host path == oracle
+    flat = np.full_like(src, 128)
+    assert np.array_equal(O.seamless_clone(flat, dst, mask, (70, 50), O.MIXED_CLONE), dst)               # (6)
+    assert not np.array_equal(O.seamless_clone(flat, dst, mask, (70, 50), O.NORMAL_CLONE), dst)
+    smooth = np.full((120, 140, 3), 100, np.uint8)
+    tex = np.clip(np.stack([128 + 100 * ((xx // 3) % 2)] * 3, -1), 0, 255).astype(np.uint8)[:40, :60]   # vertical stripes: Px != 0, Py = 0
+    assert np.array_equal(O.seamless_clone(tex, smooth, mask, (70, 50), O.MIXED_CLONE),
+                          O.seamless_clone(tex, smooth, mask, (70, 50), O.NORMAL_CLONE))                 # (7)
+    mixed = O.seamless_clone(src, dst, mask, (70, 50), O.MIXED_CLONE)
+    out3 = dst.copy()
+    P.poisson_clone_numpy(out3, src, pms, P.clone_roi(pms, (70, 50), dst.shape[:2]), mixed=True)
+    assert np.array_equal(out3, mixed) and not np.array_equal(mixed, out)                                # (8)
 
 
 def test_restated_opencv_algorithms_agree_with_independent_implementations():

@@ -9,7 +9,7 @@ import shims:
     skimage.morphology.disk(r)         boolean x^2 + y^2 <= r^2 footprint
     skimage.filters.median(img, fp)    scipy.ndimage.median_filter(footprint=fp, mode='nearest')  [what skimage itself calls]
     cv2.resize(u8, (w, h))             oracle/self_sup_ref.resize_linear_u8   -- a restatement of OpenCV's 8-bit INTER_LINEAR
-    cv2.seamlessClone(..NORMAL_CLONE)  oracle/self_sup_ref.seamless_clone     -- a restatement of OpenCV's Poisson cloning
+    cv2.seamlessClone(..NORMAL_CLONE / MIXED_CLONE)  oracle/self_sup_ref.seamless_clone  -- a restatement of OpenCV's Poisson cloning
 The first four are independent library implementations: cases that only use them pin the whole function.  The last two are
 this repository's own restatements of published OpenCV algorithms (PARITY UNPINNED, see oracle/self_sup_ref.py): the cases
 with resize=True / mode=cv2.NORMAL_CLONE -- the shipped recipe, datasets/datasets/anomaly_detection.py:118-141,254-264 --
@@ -120,6 +120,15 @@ CASES = [
                                 shift=True, same=False, label_mode="logistic-intensity", width_bounds_pct=((0.03, 0.4), (0.03, 0.4)),
                                 intensity_logistic_params=(1 / 12, 24), skip_background=None, resize_bounds=(.5, 2))),
     ("same_source", 8, dict(mode="swap", num_patches=2, resize=False, shift=True, same=True, label_mode="binary", gamma_params=(2, 0.05, 0.03))),
+    # ---- round 4: cv2.MIXED_CLONE and 'mix' (self_sup_tasks.py:22,47-48,267): the reference's coin flip + its control flow around the clone
+    ("mixed_clone", 16, dict(mode=2, num_patches=2, min_object_pct=0, min_overlap_pct=0.25, gamma_params=(2, 0.05, 0.03), resize=True,
+                             shift=True, same=False, label_mode="logistic-intensity", width_bounds_pct=((0.03, 0.4), (0.03, 0.4)),
+                             intensity_logistic_params=(1 / 12, 24))),
+    ("mix_a", 19, dict(mode="mix", num_patches=2, min_object_pct=0, min_overlap_pct=0.25, gamma_params=(2, 0.05, 0.03), resize=True,
+                       shift=True, same=False, label_mode="logistic-intensity", width_bounds_pct=((0.03, 0.4), (0.03, 0.4)))),
+    ("mix_b", 22, dict(mode="mix", num_patches=2, min_object_pct=0, min_overlap_pct=0.25, gamma_params=(2, 0.05, 0.03), resize=False,
+                       shift=True, same=False, label_mode="logistic-intensity", width_bounds_pct=((0.03, 0.4), (0.03, 0.4)),
+                       skip_background=(20, 20))),
 ]
 
 

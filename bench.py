@@ -64,7 +64,7 @@ def make_samples(B: int, vocab: int, seed: int, device):
                 before_ids=before, after_ids=after, target_ids=tgt, target_mask=torch.ones(B, 16, dtype=torch.long))
 
 
-KERNEL_NAMES = {1: "gemm_nt_kernel<128x128>", 2: "gemm_256_kernel", 3: "gemm_nt_kernel<128x64>", 4: "gemm_nt_kernel<160x128>",
+KERNEL_NAMES = {1: "gemm_nt_kernel<128x128>", 2: "gemm_x8_kernel", 3: "gemm_nt_kernel<128x64>", 4: "gemm_nt_kernel<160x128>",
                 5: "gemm_nt_kernel<160x96>", 6: "gemm_nt_kernel<64x64>"}
 GEMM_OUT_F32 = 1
 
@@ -379,8 +379,10 @@ def main():
                 # launch grids profiled here (tiles x K splits)
                 traffic = None
                 pdir = os.path.join(ROOT, "profiles")
-                tpath = next((os.path.join(pdir, f) for f in ("r03_gemm256_traffic.json", "r02_gemm256_traffic.json")
-                              if os.path.exists(os.path.join(pdir, f))), None)
+                # the NEWEST committed PMC summary (rNN[x]_gemm256_traffic.json); a lookup, not a measurement of this run:
+                # the line says so (`from_committed_profile`)
+                cands = sorted(f for f in (os.listdir(pdir) if os.path.isdir(pdir) else []) if f.endswith("_gemm256_traffic.json"))
+                tpath = os.path.join(pdir, cands[-1]) if cands else None
                 if tpath and did == 2:
                     tj = json.load(open(tpath))
                     rd = wr_ = 0.0
@@ -395,7 +397,7 @@ def main():
                     if src_n:
                         traffic = dict(bytes_per_launch=round((rd + wr_) / src_n), read=round(rd / src_n), write=round(wr_ / src_n),
                                        algorithmic_bytes_per_launch=round(dk["algorithmic_mb_per_launch"] * 1e6),
-                                       launches_matched=src_n, of_launches=dk["launches"],
+                                       launches_matched=src_n, of_launches=dk["launches"], from_committed_profile=True,
                                        source=f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                                               f"passes; read = 2 x FETCH_SIZE on gfx950)")
                 all_ms = sum(v["total_ms"] for v in per.values())

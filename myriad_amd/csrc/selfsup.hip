@@ -57,13 +57,16 @@ __global__ void patch_blend_kernel(unsigned char* __restrict__ out, const unsign
 
 __global__ void label_sum_kernel(const unsigned char* __restrict__ dest, const unsigned char* __restrict__ out,
                                  const unsigned char* __restrict__ m, int* __restrict__ sums, long npx) {
+  // low half: the channel sum of |dest - out| under the union mask (what label_mask thresholds, self_sup_tasks.py:97); high half:
+  // the same sum WITHOUT the mask -- the intensity label (:101-103) multiplies by label_mask, the median-blurred mask, which can
+  // reach pixels the union mask leaves out (holes of a background-trimmed patch that a Poisson clone nevertheless changed).
+  // Round 4 fix: both stages used the masked sum; the 'mix_b' golden (clone + skip_background, no resize) is the case that
+  // tells them apart.
   for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < npx; i += (long)gridDim.x * blockDim.x) {
     int s = 0;
-    if (m[i]) {
 #pragma unroll
-      for (int c = 0; c < 3; ++c) s += abs((int)dest[i * 3 + c] - (int)out[i * 3 + c]);
-    }
-    sums[i] = s;
+    for (int c = 0; c < 3; ++c) s += abs((int)dest[i * 3 + c] - (int)out[i * 3 + c]);
+    sums[i] = (m[i] ? s : 0) | (s << 16);
   }
 }
 
@@ -78,7 +81,7 @@ __global__ void label_mask_kernel(const int* __restrict__ sums, unsigned char* _
       const int yy = min(max(y + dy, 0), H - 1);
       for (int dx = -2; dx <= 2; ++dx) {
         const int xx = min(max(x + dx, 0), W - 1);
-        cnt += sums[base + (long)yy * W + xx] > tol3;
+        cnt += (sums[base + (long)yy * W + xx] & 0xFFFF) > tol3;
       }
     }
     lm[i] = cnt >= 13;
@@ -103,7 +106,7 @@ __global__ void label_value_kernel(const int* __restrict__ sums, const unsigned 
         if (dx * dx + dy * dy > 25) continue;
         const int xx = min(max(x + dx, 0), W - 1);
         const long j = base + (long)yy * W + xx;
-        v[n++] = lm[j] ? sums[j] : 0;
+        v[n++] = lm[j] ? (sums[j] >> 16) : 0;
       }
     }
     // 41st smallest of 81: most windows are all zero -- count first, select only when needed

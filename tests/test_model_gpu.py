@@ -284,12 +284,13 @@ def test_networks_vs_golden():
         for idx in (0, 3, 6, 9, 12, 15):
             w = st.g[pre + f"meta_net.{idx}.weight"]
             want_norm = g[f"{nm}_dw{idx}_norm"].item()
-            tol = 0.25 if idx in (0, 3) else 5e-2       # first stem layers: see stem_grad_close
-            assert abs(w.norm().item() - want_norm) < tol * want_norm, (nm, idx, w.norm().item(), want_norm)
-            if idx in (0, 3):   # 4/16-element cancelling sums: direction only (see stem_grad_close)
-                assert cos_sim(st.g[pre + f"meta_net.{idx}.bias"][:64], g[f"{nm}_db{idx}"]) >= 0.9, (nm, idx)
-            else:
-                assert stem_grad_close(st.g[pre + f"meta_net.{idx}.bias"][:64], g[f"{nm}_db{idx}"]), (nm, idx)
+            if idx in (0, 3):
+                # the first two stem layers against an fp32 forward are bounded by the reference's own bf16 gap, measured on
+                # matching inputs: test_stem_gradients_vs_the_fp32_reference_are_bounded_by_its_own_bf16_gap (this golden has
+                # no bf16-forward twin); against the bf16-forward reference they are held to 5e-2 like every other layer
+                continue
+            assert abs(w.norm().item() - want_norm) < 5e-2 * want_norm, (nm, idx, w.norm().item(), want_norm)
+            assert stem_grad_close(st.g[pre + f"meta_net.{idx}.bias"][:64], g[f"{nm}_db{idx}"]), (nm, idx)
 
 
 class _TwoIdenticalRanks:
@@ -426,6 +427,42 @@ def test_ve_net_grads_vs_reference_bf16_forward_golden():
             e_n = abs(st.g[pre + f"meta_net.{idx}.weight"].norm().item() / g[f"{nm}_dw{idx}_norm"].item() - 1.0)
             print(f"{nm} conv{idx}: dW {e_w:.3e} db {e_b:.3e} |dW| {e_n:.3e}")
             assert e_w <= 5e-2 and e_b <= 5e-2 and e_n <= 5e-2, (nm, idx, e_w, e_b, e_n)
+
+
+def test_stem_gradients_vs_the_fp32_reference_are_bounded_by_its_own_bf16_gap():
+    """VERDICT r3 item 8a.  Against the reference's plain fp32 forward the first two stem layers' gradients cannot be tight:
+    they are cancelling sums over ~1e5 positions behind five ReLU / arg-max layers, and a bf16 forward takes a few gates
+    differently.  The golden now measures that on the REFERENCE alone (tools/make_golden.py case_networks_bf16, same modules,
+    inputs and cotangents run twice): 0.02-1.7 % of the gates flip (per layer) and the reference's own stem gradients move by 7-33 %
+    (relative L2; `*_gap{idx}`, `*_gate_flip_frac`).  The HIP path is within 5e-2 of the bf16-forward reference
+    (test_ve_net_grads_vs_the_reference_run_with_bf16_forward_rounding), so against the fp32 reference it must satisfy the
+    triangle bound  |g_hip - g_fp32| <= gap + 5e-2; measured: it sits within 0.01 of the gap itself, asserted at gap + 2e-2 -- this replaces the former cosine >= 0.9 / norm +-25 % check."""
+    from myriad_amd.myriad import ParamStore
+    from myriad_amd.networks import VENet, ve_param_specs
+    g = load("networks_bf16fwd")
+    sd = gu.adapter_weights(seed=int(g["seed"][0]))
+    gen = torch.Generator().manual_seed(int(g["seed"][1]))
+    maps = torch.rand(2, 1, 224, 224, generator=gen).to(DEV)
+    ct_i = torch.randn(2, 49, 768, generator=gen).to(DEV)
+    ct_t = torch.randn(2, 18, 4096, generator=gen).to(DEV)
+    for nm, pre, k_last, dim, ct in (("instr", "VEInstructor.", 1, 768, ct_i), ("tok", "VETokenizer.", 5, 4096, ct_t[:, 9:].contiguous())):
+        flips = g[f"{nm}_gate_flip_frac"]
+        assert 0 < flips.max() < 0.03, flips                     # 0.02 % (first ReLU) .. 1.7 % (last arg-max) of the gates: what the gap is made of
+        st = ParamStore(ve_param_specs(pre, dim, k_last), DEV)
+        for name, ishape, _ in st.specs:
+            st.p[name].copy_(from_reference_layout(sd[name].to(DEV), ishape))
+        net = VENet(pre, k_last, dim, st.p, st.g, DEV)
+        net.forward(maps)
+        net.backward(ct)
+        for idx in (0, 3):
+            gap_w, gap_b = (float(v) for v in g[f"{nm}_gap{idx}"])
+            w = st.g[pre + f"meta_net.{idx}.weight"].float().cpu()
+            b = st.g[pre + f"meta_net.{idx}.bias"].float().cpu()
+            w32, b32 = torch.as_tensor(g[f"{nm}_dw{idx}_fp32"]), torch.as_tensor(g[f"{nm}_db{idx}_fp32"])
+            e_w = float((w.reshape(w32.shape) - w32).norm() / w32.norm())
+            e_b = float((b[:b32.numel()] - b32).norm() / b32.norm())
+            print(f"{nm} conv{idx}: vs fp32 reference dW {e_w:.3f} (reference's own bf16 gap {gap_w:.3f})  db {e_b:.3f} ({gap_b:.3f})")
+            assert e_w <= gap_w + 2e-2 and e_b <= gap_b + 2e-2, (nm, idx, e_w, gap_w, e_b, gap_b)     # measured excess <= 0.010
 
 
 def test_ve_net_grads_vs_bf16_forward_emulation():

@@ -25,7 +25,7 @@ def load(counter):
             key = (name, gy if "gemm" in name else 0)
             agg[key][0] += 1
             agg[key][1] += float(r["Counter_Value"])
-            if "gemm_256" in name:                    # keyed "tiles x K splits": the launch grids bench.py's profiler reports
+            if "gemm_256" in name or "gemm_x8" in name or "gemm_x4" in name:                    # keyed "tiles x K splits": the launch grids bench.py's profiler reports
                 e = by_grid.setdefault(counter, {}).setdefault(f"{gx_of.get(r['Dispatch_Id'], 0)}x{gy}", [0, 0.0])
                 e[0] += 1
                 e[1] += float(r["Counter_Value"])
@@ -44,7 +44,7 @@ print("|---|---|---|---|---|---|")
 for (name, gy), n, rd, wb in rows[:24]:
     print(f"| `{name}` | {gy or ''} | {n} | {rd / 1e6:.1f} | {wb / 1e6:.1f} | {(rd + wb) * n / 1e9:.2f} |")
 if "--json" in sys.argv:
-    dom = [r for r in rows if "gemm_256" in r[0][0]]
+    dom = [r for r in rows if "gemm_x8" in r[0][0]] or [r for r in rows if "gemm_256" in r[0][0]]
     if dom:
         (name, gy), n, rd, wb = dom[0]
         grids = {}
@@ -54,5 +54,5 @@ if "--json" in sys.argv:
                          "write_bytes_per_launch": wtot * 1024 / max(1, wcnt)}
         json.dump({"kernel": name, "launches": n, "read_bytes_per_launch": rd, "write_bytes_per_launch": wb,
                    "traffic_bytes_per_launch": rd + wb, "by_grid": grids,
-                   "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only); read = 2 x FETCH_SIZE KiB (gfx950), write = WRITE_SIZE KiB; gemm_256_kernel launches of python bench.py --steps 2 --warmup 1 --no-probe, by launch grid (tiles x K splits)"},
+                   "method": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only); read = 2 x FETCH_SIZE KiB (gfx950), write = WRITE_SIZE KiB; plan-kernel-2 GEMM (gemm_x8_kernel; gemm_256_kernel before round 4) launches of python bench.py --steps 2 --warmup 1 --no-probe, by launch grid (tiles x K splits)"},
                   open(sys.argv[sys.argv.index("--json") + 1], "w"), indent=1)

@@ -22,7 +22,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 P = os.path.join(ROOT, "profiles")
 PEAK = 2500.0
-KERNEL = "gemm_256_kernel"
+KERNEL = "gemm_x8_kernel" if rnd >= "r04" else "gemm_256_kernel"     # plan kernel 2 (round 4: the hand-scheduled 64-deep loop)
 
 flops, launches = 0.0, 0
 for r in csv.DictReader(open(os.path.join(P, f"{rnd}_step_gemm_shapes.csv"))):

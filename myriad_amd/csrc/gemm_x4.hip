@@ -361,10 +361,15 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__
     int4v_t voa, vob;
     const int swz = (4 * (wave & 1) + (lane >> 4)) & 7;
     const int ch = ((lane & 7) ^ swz) << 4;
+#if X4_NVARIANTS > 1
+    const int m0l = (flags & 0x40000000) ? 0 : m0, n0l = (flags & 0x40000000) ? 0 : n0;   // sweep builds: same-panel timing probe
+#else
+    const int m0l = m0, n0l = n0;
+#endif
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = (wave + 8 * i) * 8 + (lane >> 3);
-      int ra = m0 + row, rb = n0 + row;
+      int ra = m0l + row, rb = n0l + row;
       ra = ra < M ? ra : M - 1;
       rb = rb < N ? rb : N - 1;
       voa[i] = ra * lda * 2 + ch;
@@ -412,7 +417,8 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__
   }
 }
 
-static int x4_variant = 0;
+static int x4_variant = 0, x4_same_panel = 0;
+extern "C" void mhdbg_set_gemm_x4_same_panel(int on) { x4_same_panel = on; }                                   // sweep tool only
 extern "C" void mhdbg_set_gemm_x4_variant(int v) { x4_variant = (v >= 0 && v < X4_NVARIANTS) ? v : 0; }   // sweep tool only
 extern "C" int mhdbg_gemm_x4_nvariants() { return X4_NVARIANTS; }
 
@@ -429,6 +435,7 @@ int mh_launch_gemm_x4(const void* A, int lda, const void* B, int ldb, void* C, i
   const int tiles_m = (M + X4_BM - 1) / X4_BM, tiles_n = (N + X4_BN - 1) / X4_BN;
   const size_t shmem = 2 * X4_BUF;   // 128 KiB -> one 4-wave workgroup per CU
   const dim3 grid(tiles_m * tiles_n, splits);
+  if (x4_same_panel) flags |= 0x40000000;
   if (g_mh_prof_on) mh_prof_pre(stream, 2, M, N, K, splits, flags);
 #define X4_LAUNCH(V)                                                                                                           \
   {                                                                                                                            \

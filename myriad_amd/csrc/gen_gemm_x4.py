@@ -47,18 +47,15 @@ X8 = dict(waves=8, rd=1, dma=4, mid=14, end=50, fine=1, ko="")
 DEFAULT = X8        # shipped: tools/gemm_x4_sweep.py, profiles/r04_gemm_x4.md
 SWEEP = [
     dict(X8),
-    dict(X4),
-    dict(X8, mid=18),
-    dict(X8, dma=2),
-    dict(X8, dma=4),
-    dict(X8, mid=12),
-    dict(X8, rd=2, mid=24),
-    dict(X8, fine=0),
+    dict(X8, ko="nowait"),
+    dict(X8, ko="nowait bar"),
     dict(X8, ko="bar"),
     dict(X8, ko="dma"),
     dict(X8, ko="rd"),
-    dict(X8, ko="dma rd bar"),
     dict(X8, ko="mfma"),
+    dict(X8, ko="mfma rd"),
+    dict(X8, ko="mfma dma"),
+    dict(X8, ko="mfma nowait"),
 ]
 
 # register map per geometry (VGPR numbers): fragment bases of k-half 0 / 1, request offsets, fragment-row LDS addresses
@@ -139,7 +136,10 @@ def body(kind, V):
     g = GEO[waves]
     extras[nslot // 2] += [f"v_xor_b32 v{r}, 0x10000, v{r}" for r in (g["RA0"], g["RA1"], g["RB0"], g["RB1"])]
     if kind != "last":
-        extras[end].append(f"s_waitcnt vmcnt({nreq})" if (kind == "steady" and "dma" not in ko) else "s_waitcnt vmcnt(0)")
+        if "nowait" in ko:       # timing probe: never wait for the k-tile that is about to be read (stale LDS, wrong results)
+            extras[end].append(f"s_waitcnt vmcnt({2 * nreq})")
+        else:
+            extras[end].append(f"s_waitcnt vmcnt({nreq})" if (kind == "steady" and "dma" not in ko) else "s_waitcnt vmcnt(0)")
         if "bar" not in ko:
             extras[end].append("s_barrier")
         if "rd" not in ko:

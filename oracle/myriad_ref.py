@@ -387,7 +387,7 @@ def _embed_key(sd: SD) -> str:
 def greedy_generate(sd: SD, inputs_embeds: Tensor, heads: int, max_new_tokens: int = 90,
                     stop_ids: Sequence[Sequence[int]] = ((835,), (2277, 29937)), eos_id: int = 2,
                     min_length: int = 1, eps: float = 1e-6, prefix: str = "llama_model.",
-                    return_margins: bool = False):
+                    return_margins: bool = False, return_scales: bool = False):
     """`Myriad.generate` myriad.py:447-450 -> HF sample loop with do_sample, top_p=0.01, T=1
     (evaluation_aqa_dataset.py:289-301), restated as arg-max (== top-p 0.01 sampling whenever
     p_max >= 0.01), `prepare_inputs_for_generation` modeling_llama.py:730-760
@@ -401,7 +401,7 @@ def greedy_generate(sd: SD, inputs_embeds: Tensor, heads: int, max_new_tokens: i
     past = None
     x = inputs_embeds
     out: List[Tensor] = []
-    margins = []
+    margins, scales = [], []
     unfinished = torch.ones(B, dtype=torch.long)
     total = S0
     for step in range(max_new_tokens):
@@ -415,6 +415,8 @@ def greedy_generate(sd: SD, inputs_embeds: Tensor, heads: int, max_new_tokens: i
             logits[:, eos_id] = -float("inf")
         top2 = logits.topk(2, dim=-1).values
         margins.append((top2[:, 0] - top2[:, 1]))
+        scales.append(logits[torch.isfinite(logits).all(-1)].abs().amax(-1) if torch.isfinite(logits).all() else
+                      torch.where(torch.isfinite(logits), logits, torch.zeros_like(logits)).abs().amax(-1))
         nxt = logits.argmax(-1)
         nxt = nxt * unfinished + eos_id * (1 - unfinished)  # HF pads finished rows with pad(=eos)
         unfinished = unfinished * (nxt != eos_id).long()
@@ -427,6 +429,8 @@ def greedy_generate(sd: SD, inputs_embeds: Tensor, heads: int, max_new_tokens: i
         x = ew[nxt][:, None]
         total += 1
     ids = torch.stack(out, dim=1)
+    if return_scales:          # + the largest |logit| of every step: the scale a bf16 ulp is measured against
+        return ids, torch.stack(margins, dim=1), torch.stack(scales, dim=1)
     if return_margins:
         return ids, torch.stack(margins, dim=1)
     return ids

@@ -39,11 +39,18 @@ for (M, N, K) in SHAPES + [(4096, 4096, k) for k in KS]:
     for v in range(nv):
         L.mhdbg_set_gemm_x4_variant(v)
         data[(M, N, K, v)] = timeit(a, bs, out)
+    if "--same-panel" in sys.argv:               # every workgroup stages tile (0, 0)'s panels: all requests hit in L2
+        L.mhdbg_set_gemm_x4_same_panel(1)
+        for v in range(nv):
+            L.mhdbg_set_gemm_x4_variant(v)
+            data[(M, N, K, 100 + v)] = timeit(a, bs, out)
+        L.mhdbg_set_gemm_x4_same_panel(0)
     del bs
 L.mhdbg_set_gemm_x4_variant(0); L.mhdbg_set_gemm256_impl(-1)
 hdr = "| variant | " + " | ".join(f"{m}x{n}x{k}" for (m, n, k) in SHAPES) + " | us / k-tile (64) | fixed us |"
 print(hdr); print("|" + "---|" * (len(SHAPES) + 3))
-for v in range(-1, nv):
+rows = list(range(-1, nv)) + ([100 + v for v in range(nv)] if "--same-panel" in sys.argv else [])
+for v in rows:
     cells = []
     for (M, N, K) in SHAPES:
         t = data[(M, N, K, v)]
@@ -52,4 +59,4 @@ for v in range(-1, nv):
     xs = [k / 64 for k in KS]; ys = [data[(4096, 4096, k, v)] for k in KS]
     n = len(xs); mx = sum(xs) / n; my = sum(ys) / n
     b = sum((x - mx) * (y - my) for x, y in zip(xs, ys)) / sum((x - mx) ** 2 for x in xs); a0 = my - b * mx
-    print(f"| {'8-wave' if v < 0 else v} | " + " | ".join(cells) + f" | {b:.3f} | {a0:.1f} |", flush=True)
+    print(f"| {'8-wave' if v < 0 else (v if v < 100 else f'{v - 100} same-panel')} | " + " | ".join(cells) + f" | {b:.3f} | {a0:.1f} |", flush=True)

@@ -43,7 +43,13 @@ struct mh_ctx {
 static void* open_rccl() {
   static void* handle = nullptr;
   if (handle) return handle;
-  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
+  // a host framework that already brought an RCCL into the process (PyTorch-ROCm ships its own): use THAT image -- one
+  // bootstrap, one set of IPC handles per process -- before loading another copy from the search path
+  for (const char* n : names) {
+    void* h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD | RTLD_NODELETE);
+    if (h) { handle = h; return h; }
+  }
   for (const char* n : names) {
     void* h = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NODELETE);
     if (h) { handle = h; return h; }

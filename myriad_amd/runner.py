@@ -178,6 +178,13 @@ class DataParallel:
                 import warnings
                 warnings.warn(f"mh_ctx gradient exchange unavailable ({e}); using torch.distributed")
                 self.ctx = None
+            # the choice has to be the same on every rank (a rank on torch.distributed and a rank on the context would wait for
+            # each other forever): agree through the process group, fall back everywhere if anyone fell back
+            ok = torch.tensor([1.0 if self.ctx is not None else 0.0], device=device)
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if float(ok.item()) == 0.0 and self.ctx is not None:
+                self.ctx.close()
+                self.ctx = None
 
     def _persistent(self, key: str, n: int, dtype, device) -> torch.Tensor:
         """Exchange staging buffers are allocated once per (purpose, size, dtype) and reused every step."""

@@ -60,6 +60,10 @@ def load() -> ctypes.CDLL:
         raise MyriadHipError(
             f"{LIB_PATH} not found. The MI355X HIP library is required (no CPU / eager fallback exists). "
             "Build it with `python -m myriad_amd.build` (hipcc --offload-arch=gfx950).")
+    # The host framework's HIP runtime first: PyTorch-ROCm ships its own libamdhip64 and the process must hold ONE runtime --
+    # loading this library before torch pulls in /opt/rocm's copy, and kernels registered with one runtime cannot be launched on
+    # the other's streams (seen as MH_ERR_LAUNCH at the first launch when build() ran before smoke() in one process).
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in signatures().items():
         try:

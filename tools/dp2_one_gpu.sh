@@ -1,7 +1,8 @@
 #!/bin/bash
 # Two data-parallel ranks on ONE GPU (gloo between the processes, both on cuda:0): exercises the N > 1 control flow of
 # bench.py / runner.DataParallel -- both exchange modes, both wire dtypes -- on a single-GPU box.  It is a control-flow
-# harness, not an RCCL measurement (RCCL refuses two ranks per device); run it through gpurun.
+# harness, not an RCCL measurement (RCCL refuses two ranks per device); run it through gpurun.  (Round 4: the same control flow
+# is a test now -- tests/test_dp_gpu.py, bit-compared with a one-process run; this script remains the full-width bench variant.)
 O=gpurun_out/dp2; mkdir -p $O
 export MYRIAD_DIST_BACKEND=gloo MYRIAD_SINGLE_DEVICE=1
 for MODE in allreduce rs_ag; do for GD in f32 bf16; do

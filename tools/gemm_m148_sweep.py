@@ -50,6 +50,14 @@ for (M, N, K) in SHAPES:
                 continue
             L.mhdbg_set_force_plan(kid, s)
             line += f" k{kid}s{s}:{timeit(lambda b: ops.gemm(a, b, out=out), bs):.0f}"
+    for s in (1, 2, 3, 4, 5, 6, 8, 10, 12):          # round 4: the 256 x 256 eight-wave kernel on the same rows
+        if K // s < 256:
+            continue
+        wg = ((M + 255) // 256) * ((N + 255) // 256) * s
+        if wg > 300 or wg < 60:
+            continue
+        L.mhdbg_set_force_plan(2, s)
+        line += f" k2s{s}:{timeit(lambda b: ops.gemm(a, b, out=out), bs):.0f}"
     L.mhdbg_set_force_plan(-1, 0)
     print(line, flush=True)
     del bs

@@ -10,5 +10,6 @@ python tools/rocpd_stats.py $DB 8 > $O/kernel_trace.md 2>&1
 python tools/rocpd_step.py $DB > $O/step_breakdown.md 2>&1
 python tools/rocpd_gaps.py $DB > $O/step_gaps.md 2>&1
 python tools/rocpd_llama_chain.py $DB > $O/llama_chain.md 2>&1
+python tools/rocpd_timeline.py $DB 250 ${TIMELINE_ARGS} > $O/step_timeline.md 2>&1
 rm -rf $O/kt
 cat $O/llama_chain.md

@@ -154,6 +154,14 @@ int mh_gemm_swiglu_bwd(const void* dH, int lddh, const void* WdT, int ldw, const
 /* erf-GELU on bf16 (Qformer.py:352-356 via ACT2FN["gelu"]) */
 int mh_gelu_fwd(const void* x, void* y, long n, mh_stream_t s);
 int mh_gelu_bwd(const void* dy, const void* x, void* dx, long n, mh_stream_t s);
+/* the erf-GELU MLP (Qformer.py:481-484: intermediate_query -> gelu -> output_query; eva_vit.py:54-61) with the elementwise half in
+   the epilogue of the GEMM next to it: pre[M, N] = X W^T + bias (bf16, kept for the backward) and act = gelu(pre) in one launch;
+   dpre = bf16(dY WT^T) * gelu'(pre) in one launch.  Fused when the policy runs an unsplit tile kernel, otherwise GEMM + mh_gelu_*
+   (dact_buf [M, N] bf16: scratch for that case; dense rows required then).  Same bits as the separate launches. */
+int mh_gemm_gelu_fwd(const void* X, int ldx, const void* W, int ldw, const float* bias, void* pre, int ldpre, void* act, int ldact,
+                     int M, int N, int K, mh_stream_t s);
+int mh_gemm_gelu_bwd(const void* dY, int lddy, const void* WT, int ldw, const void* pre, int ldpre, void* dpre, int lddpre,
+                     void* dact_buf, int M, int N, int K, mh_stream_t s);
 
 /* counter-based dropout for PEFT lora_dropout (myriad.py:171-178): mask = f(seed, flat index); bwd regenerates it */
 int mh_dropout_bf16(const void* x, long ldx, void* y, long ldy, long rows, int cols, float p, unsigned long long seed,

@@ -25,6 +25,8 @@
 #define MH_GEMM_OUT_F32 1
 #define MH_GEMM_GELU 2
 #define MH_GEMM_REGSTAGE 4
+#define MH_GEMM_GELU_PRE 64    // internal (mh_gemm_gelu_fwd): aux <- bf16 pre-activation, C <- gelu of it
+#define MH_GEMM_GELU_BWD 128   // internal (mh_gemm_gelu_bwd): C <- bf16(product) * gelu'(aux)
 #define MH_GEMM_VARIANT_SHIFT 8  // bits 8..11: 0 = auto, 1 = 2-stage/128, 2 = 4-stage/128, 3 = 3-stage/64, 4 = 2-stage/64
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void gemm_nt_kernel(const b
                                                             const float* __restrict__ bias, const float* res, int M,
                                                             int N, int K, int lda, int ldb, int ldc, int ldr, int flags,
                                                             float alpha, int tiles_m, int kt_per_split,
-                                                            long split_stride) {
+                                                            long split_stride, void* aux, int ldaux) {
   constexpr int BK = TBK;
   constexpr int CPR = TBK / 8;                 // 16-B chunks per tile row
   constexpr int NJ = TBN / 32;                 // 16-wide N fragments per wave
@@ -209,6 +211,10 @@ __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void gemm_nt_kernel(const b
   // epilogue: lane owns C[m][n .. n+3] for m = m0+wm*64+i*16+lr, n = n0+wn*(TBN/2)+j*16+lg*4
   const bool out_f32 = flags & MH_GEMM_OUT_F32;
   const bool do_gelu = flags & MH_GEMM_GELU;
+  // GELU pair around an MLP (mh_gemm_gelu_fwd / _bwd): the pre-activation is rounded to bf16 and kept in `aux` (forward), the
+  // incoming gradient is rounded to bf16 and multiplied by gelu'(aux) (backward) -- the bits of GEMM -> gelu_fwd / gelu_bwd
+  const bool gelu_pre = flags & MH_GEMM_GELU_PRE, gelu_bwd = flags & MH_GEMM_GELU_BWD;
+  bf16_t* auxp = reinterpret_cast<bf16_t*>(aux);
 #pragma unroll
   for (int i = 0; i < MI; ++i) {
     const int m = m0 + wm * (MI * 16) + i * 16 + lr;
@@ -222,6 +228,19 @@ __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void gemm_nt_kernel(const b
         if (bias) {
           const float4_t b4 = *reinterpret_cast<const float4_t*>(bias + n);
           v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+        }
+        if (gelu_pre) {
+          uint2 pk;
+          pk.x = pack_bf2(v[0], v[1]);
+          pk.y = pack_bf2(v[2], v[3]);
+          *reinterpret_cast<uint2*>(auxp + (size_t)m * ldaux + n) = pk;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = gelu_erf(bf2f(f2bf(v[e])));
+        }
+        if (gelu_bwd) {
+          const short4_t x4 = *reinterpret_cast<const short4_t*>(auxp + (size_t)m * ldaux + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = bf2f(f2bf(v[e])) * gelu_erf_grad(bf2f((bf16_t)x4[e]));
         }
         if (do_gelu) {
 #pragma unroll
@@ -244,6 +263,11 @@ __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void gemm_nt_kernel(const b
         for (int e = 0; e < 4 && n + e < N; ++e) {
           float x = v[e];
           if (bias) x += bias[n + e];
+          if (gelu_pre) {
+            auxp[(size_t)m * ldaux + n + e] = f2bf(x);
+            x = gelu_erf(bf2f(f2bf(x)));
+          }
+          if (gelu_bwd) x = bf2f(f2bf(x)) * gelu_erf_grad(bf2f(auxp[(size_t)m * ldaux + n + e]));
           if (do_gelu) x = gelu_erf(x);
           if (res) x += res[(size_t)m * ldr + n + e];
           if (out_f32) reinterpret_cast<float*>(Cv)[(size_t)m * ldc + n + e] = x;
@@ -257,6 +281,7 @@ __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void gemm_nt_kernel(const b
 struct GemmArgs {
   const void* A; int lda; const void* B; int ldb; void* C; int ldc; int M, N, K;
   const float* bias; const float* residual; int ldr; int flags; float alpha; int splits, tps; long split_stride;
+  void* aux; int ldaux;        // MH_GEMM_GELU_PRE / _BWD operand (NULL otherwise)
 };
 
 template <int STAGING, int NST, int TBN, int MINB, int TBK = 64, int NW = 4, int TBM = BM>
@@ -274,7 +299,7 @@ static int launch_gemm(const GemmArgs& g, hipStream_t stream) {
   // tps / kt_per_split are in units of 64-deep K tiles at the call sites; rescale for 32-deep kernels
   hipLaunchKernelGGL((gemm_nt_kernel<STAGING, NST, TBN, MINB, TBK, NW, TBM>), grid, block, shmem, stream, (const bf16_t*)g.A,
                      (const bf16_t*)g.B, g.C, g.bias, g.residual, g.M, g.N, g.K, g.lda, g.ldb, g.ldc, g.ldr, g.flags,
-                     g.alpha, tiles_m, g.tps * (64 / TBK), g.split_stride);
+                     g.alpha, tiles_m, g.tps * (64 / TBK), g.split_stride, g.aux, g.ldaux);
   if (g_mh_prof_on) mh_prof_post(stream);
   MH_CHECK_LAUNCH();
   return MH_OK;
@@ -884,6 +909,60 @@ extern "C" int mh_gemm_swiglu_bwd(const void* dH, int lddh, const void* WdT, int
   const int rc = mh_gemm_bf16_nt(dH, lddh, WdT, ldw, dact_buf, I, M, I, K, nullptr, nullptr, 0, 0, 1.0f, stream);
   if (rc) return rc;
   return mh_silu_mul_bwd_blk(dact_buf, gu, dgu, M, I, 128, stream);
+}
+
+// ---- erf-GELU MLP (Qformer.py:481-484 intermediate_query / output_query, eva_vit.py:54-61) fused into the two GEMMs around it ----
+// Forward: pre[M, N] = X . W^T + bias (bf16, saved for the backward) and act = gelu(pre); backward: dpre = dact * gelu'(pre) with
+// dact = dY . WT^T rounded to bf16.  When the plan runs one of the unsplit LDS-DMA tile kernels (plan kernels 1 / 3 / 6: the
+// Q-Former's 648-row products) the elementwise half rides that launch's epilogue; otherwise GEMM and elementwise kernel run back
+// to back -- the same bits either way (the epilogue rounds to bf16 where the separate launches do).  One launch less per
+// direction per BertLayer on a chain of ~400 dependent 5-15-us launches.
+extern "C" int mh_gelu_fwd(const void* x, void* y, long n, hipStream_t stream);
+extern "C" int mh_gelu_bwd(const void* dy, const void* x, void* dx, long n, hipStream_t stream);
+static int g_gelu_fused = -1;
+extern "C" void mhdbg_set_gelu_fused(int on) { g_gelu_fused = on ? 1 : 0; }   // debug hook (tests), not part of the ABI
+
+static bool gelu_fusable(int M, int N, int K, int* variant) {
+  if (g_gelu_fused < 0) { const char* e = getenv("MYRIAD_GELU_FUSED"); g_gelu_fused = (e && e[0] == '0') ? 0 : 1; }
+  int kernel = 1, splits = 1;
+  gemm_plan(M, N, K, 0, &kernel, &splits);
+  *variant = plan_variant(kernel);
+  return g_gelu_fused && splits == 1 && (kernel == 1 || kernel == 3 || kernel == 6);
+}
+
+extern "C" int mh_gemm_gelu_fwd(const void* X, int ldx, const void* W, int ldw, const float* bias, void* pre, int ldpre, void* act,
+                                int ldact, int M, int N, int K, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return MH_OK;
+  if (!pre || !act || K <= 0 || (K % 64) || (ldx % 8) || (ldw % 8) || (ldpre % 4) || (ldact % 4) || ldpre < N || ldact < N) return MH_ERR_ARG;
+  if (((uintptr_t)X | (uintptr_t)W | (uintptr_t)pre | (uintptr_t)act) & 15) return MH_ERR_ARG;
+  int variant = 0;
+  if (gelu_fusable(M, N, K, &variant)) {
+    GemmArgs g = {X, ldx, W, ldw, act, ldact, M, N, K, bias, nullptr, 0, MH_GEMM_GELU_PRE | (variant << MH_GEMM_VARIANT_SHIFT), 1.0f,
+                  1, K / 64, 0L, pre, ldpre};
+    return dispatch(g, stream);
+  }
+  if (ldpre != N || ldact != N || (((long)M * N) % 8)) return MH_ERR_ARG;        // the elementwise kernels take dense rows
+  const int rc = mh_gemm_bf16_nt(X, ldx, W, ldw, pre, ldpre, M, N, K, bias, nullptr, 0, 0, 1.0f, stream);
+  if (rc) return rc;
+  return mh_gelu_fwd(pre, act, (long)M * N, stream);
+}
+
+// dact_buf [M, N] bf16 is scratch for the unfused case (may be NULL when the caller knows the plan fuses: then MH_ERR_ARG if not)
+extern "C" int mh_gemm_gelu_bwd(const void* dY, int lddy, const void* WT, int ldw, const void* pre, int ldpre, void* dpre, int lddpre,
+                                void* dact_buf, int M, int N, int K, hipStream_t stream) {
+  if (M <= 0 || N <= 0) return MH_OK;
+  if (!pre || !dpre || K <= 0 || (K % 64) || (lddy % 8) || (ldw % 8) || (ldpre % 4) || (lddpre % 4) || ldpre < N || lddpre < N) return MH_ERR_ARG;
+  if (((uintptr_t)dY | (uintptr_t)WT | (uintptr_t)pre | (uintptr_t)dpre) & 15) return MH_ERR_ARG;
+  int variant = 0;
+  if (gelu_fusable(M, N, K, &variant)) {
+    GemmArgs g = {dY, lddy, WT, ldw, dpre, lddpre, M, N, K, nullptr, nullptr, 0, MH_GEMM_GELU_BWD | (variant << MH_GEMM_VARIANT_SHIFT),
+                  1.0f, 1, K / 64, 0L, const_cast<void*>(pre), ldpre};
+    return dispatch(g, stream);
+  }
+  if (!dact_buf || ldpre != N || lddpre != N || (((long)M * N) % 8)) return MH_ERR_ARG;
+  const int rc = mh_gemm_bf16_nt(dY, lddy, WT, ldw, dact_buf, N, M, N, K, nullptr, nullptr, 0, 0, 1.0f, stream);
+  if (rc) return rc;
+  return mh_gelu_bwd(dact_buf, pre, dpre, (long)M * N, stream);
 }
 
 // ---- explicit split-K entry (wgrad of the conv stem: M,N small, K huge); caller passes the scratch ----

@@ -530,6 +530,34 @@ def gemm_swiglu_bwd(dh: torch.Tensor, wdT: torch.Tensor, gu: torch.Tensor):
     return dgu
 
 
+def gemm_gelu_fwd(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None):
+    """(pre [M, N] bf16 = x @ w^T + bias, act = gelu(pre)): the MLP's first product with the GELU in its epilogue (separate
+    launches, same bits, when the policy does not run an unsplit tile kernel)."""
+    _chk2d(x, BF16, "gemm_gelu_fwd.x")
+    _chk2d(w, BF16, "gemm_gelu_fwd.w")
+    M, K = x.shape
+    N = w.shape[0]
+    pre = torch.empty((M, N), dtype=BF16, device=x.device)
+    act = torch.empty((M, N), dtype=BF16, device=x.device)
+    rc = _L().mh_gemm_gelu_fwd(_p(x), x.stride(0), _p(w), w.stride(0), _p(bias), _p(pre), N, _p(act), N, M, N, K, _s())
+    _lib.check(rc, f"mh_gemm_gelu_fwd M={M} N={N} K={K}")
+    return pre, act
+
+
+def gemm_gelu_bwd(dy: torch.Tensor, wT: torch.Tensor, pre: torch.Tensor):
+    """dpre [M, N] bf16 = bf16(dy @ wT^T) * gelu'(pre): the MLP's second dgrad with the GELU backward in its epilogue."""
+    _chk2d(dy, BF16, "gemm_gelu_bwd.dy")
+    _chk2d(wT, BF16, "gemm_gelu_bwd.wT")
+    _chk2d(pre, BF16, "gemm_gelu_bwd.pre")
+    M, K = dy.shape
+    N = wT.shape[0]
+    dpre = torch.empty((M, N), dtype=BF16, device=dy.device)
+    dact = torch.empty((M, N), dtype=BF16, device=dy.device)
+    rc = _L().mh_gemm_gelu_bwd(_p(dy), dy.stride(0), _p(wT), wT.stride(0), _p(pre), pre.stride(0), _p(dpre), N, _p(dact), M, N, K, _s())
+    _lib.check(rc, f"mh_gemm_gelu_bwd M={M} N={N} K={K}")
+    return dpre
+
+
 def gelu_fwd(x):
     y = torch.empty_like(x)
     _lib.check(_L().mh_gelu_fwd(_p(x), _p(y), x.numel(), _s()), "mh_gelu_fwd")

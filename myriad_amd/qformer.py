@@ -107,8 +107,7 @@ class QFormerHIP:
                 yc = ops.gemm(cctx.view(M, D), L["cwo"], bias=L["cbo"], residual=h, out_dtype=F32)
                 hb, h = ops.layernorm_fwd(yc, L["ln_c_w"], L["ln_c_b"], self.eps, want_bf16=True, want_f32=True)
                 s.update(cq=cq, ckv=ckv, cctx=cctx, clse=clse, y_c=yc)
-            pre = ops.gemm(hb, L["w1"], bias=L["b1"])
-            act = ops.gelu_fwd(pre)
+            pre, act = ops.gemm_gelu_fwd(hb, L["w1"], L["b1"])       # GELU in the product's epilogue (one launch)
             yf = ops.gemm(act, L["w2"], bias=L["b2"], residual=h, out_dtype=F32)
             hb, h = ops.layernorm_fwd(yf, L["ln_f_w"], L["ln_f_b"], self.eps, want_bf16=True, want_f32=True)
             s.update(pre=pre, y_f=yf)
@@ -131,8 +130,7 @@ class QFormerHIP:
         for L, s in zip(reversed(self.layers), reversed(sv["layers"])):
             # FFN:  h_out = LN(y_f),  y_f = act(h W1^T+b1) W2^T + b2 + h
             dy, dyb = ops.layernorm_bwd(dh, s["y_f"], L["ln_f_w"], self.eps, want_bf16=True)
-            dact = ops.gemm(dyb, L["w2T"])
-            dpre = ops.gelu_bwd(dact, s["pre"])
+            dpre = ops.gemm_gelu_bwd(dyb, L["w2T"], s["pre"])        # gelu'(pre) in the dgrad's epilogue (one launch)
             dh = ops.gemm(dpre, L["w1T"], residual=dy, out_dtype=F32)
             if L["cross"]:
                 dy, dyb = ops.layernorm_bwd(dh, s["y_c"], L["ln_c_w"], self.eps, want_bf16=True)

@@ -483,6 +483,45 @@ def _swiglu_case(M, I, K):
     assert relerr(d3[:, :, 0].reshape(M, I), g32.grad) < 2e-2 and relerr(d3[:, :, 1].reshape(M, I), u32.grad) < 2e-2
 
 
+@pytest.mark.parametrize("M,N,K,D", [(648, 3072, 768, 768), (81, 3072, 768, 768), (257, 768, 256, 128), (50, 132, 64, 64),
+                                     (2056, 6144, 1408, 1408), (16, 3072, 768, 768)])
+def test_gelu_fused_into_the_mlp_gemms(M, N, K, D):
+    """mh_gemm_gelu_fwd/bwd (erf-GELU in the first product's epilogue with the pre-activation kept, gelu' in the second dgrad's
+    epilogue: Qformer.py:481-484) against an fp32 torch model and bit-for-bit against GEMM + mh_gelu_fwd / mh_gelu_bwd -- on the
+    plan kernels that fuse (648 / 81 / 257 / 50 rows: 128x64, 64x64 and 128x128 tiles, ragged edges) and on shapes whose plan
+    does not (the ViT's 256-tile product, a 16-row GEMV), where the entry points run the two launches themselves."""
+    import ctypes
+    from myriad_amd import _lib as L
+    hook = ctypes.CDLL(L.LIB_PATH).mhdbg_set_gelu_fused
+    ops.ensure_workspace(torch.device(DEV))
+    x = bf(rnd(M, K, seed=171, scale=0.5)).to(DEV)
+    w1 = bf(rnd(N, K, seed=172, scale=0.08)).to(DEV)
+    b1 = rnd(N, seed=173, scale=0.3).to(DEV)
+    dy = bf(rnd(M, D, seed=174, scale=0.1)).to(DEV)
+    w2T = bf(rnd(N, D, seed=175, scale=0.05)).to(DEV)
+    res = {}
+    for fused in (1, 0):
+        hook(fused)
+        try:
+            pre, act = ops.gemm_gelu_fwd(x, w1, b1)
+            dpre = ops.gemm_gelu_bwd(dy, w2T, pre)
+        finally:
+            hook(1)
+        res[fused] = (pre, act, dpre)
+    for a, b in zip(res[1], res[0]):
+        assert torch.equal(a, b)
+    pre, act, dpre = res[1]
+    pre2 = ops.gemm(x, w1, bias=b1)                        # and against the public separate launches
+    assert torch.equal(pre, pre2) and torch.equal(act, ops.gelu_fwd(pre2))
+    assert torch.equal(dpre, ops.gelu_bwd(ops.gemm(dy, w2T), pre2))
+    pre_ref = x.float() @ w1.float().T + b1
+    assert relerr(pre.float(), pre_ref) < 6e-3
+    assert relerr(act.float(), F.gelu(pre_ref)) < 1.2e-2
+    p32 = pre.float().clone().requires_grad_(True)
+    (F.gelu(p32) * (dy.float() @ w2T.float().T)).sum().backward()
+    assert relerr(dpre.float(), p32.grad) < 1.2e-2
+
+
 def _rope_tables(D, max_pos=256):
     inv = 1.0 / (10000.0 ** (torch.arange(0, D, 2).float() / D))
     fr = torch.einsum("i,j->ij", torch.arange(max_pos).float(), inv)

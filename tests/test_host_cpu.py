@@ -100,7 +100,8 @@ def _dp_worker(rank, world, port, q):
     dp = DataParallel(device=None)
     assert dp.world == world and dp.rank == rank
     dp.allreduce(flat)
-    q.put((rank, mine, flat))
+    q.put((rank, mine.numpy().copy(), flat.numpy().copy()))          # by value: a tensor travels as an fd the parent must fetch
+                                                                      # while this process is still alive
     dp.barrier()
     dist.destroy_process_group()
 
@@ -115,7 +116,7 @@ def test_gradient_allreduce_world2_gloo():
     got = {}
     for _ in range(2):
         r, mine, red = q.get(timeout=120)
-        got[r] = (mine, red)
+        got[r] = (torch.from_numpy(mine), torch.from_numpy(red))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0
@@ -140,7 +141,7 @@ def _dp_flags_worker(rank, world, port, q):
     st.used.copy_(torch.tensor([1.0 if m in used else 0.0 for m in st.modules]))
     dp = DataParallel(device=None)
     dp.allreduce(st.flat_g_comm)                       # ONE exchange carries gradients and use flags
-    q.put((rank, st.modules, st.used.clone(), st.flat_g.clone()))
+    q.put((rank, list(st.modules), st.used.numpy().copy(), st.flat_g.numpy().copy()))     # by value (see _dp_worker)
     dp.barrier()
     dist.destroy_process_group()
 
@@ -158,7 +159,7 @@ def test_module_use_flags_ride_the_gradient_allreduce_world2_gloo():
     got = {}
     for _ in range(2):
         r, modules, used, grad = q.get(timeout=120)
-        got[r] = (modules, used, grad)
+        got[r] = (modules, torch.from_numpy(used), torch.from_numpy(grad))
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

@@ -239,7 +239,7 @@ def _dp_world4_worker(rank, world, port, q):
     # ragged use: the prompt stage is drawn per rank (myriad.py:378): tokenizer on ranks 0 and 3, instructor on rank 1 only,
     # adaptor everywhere, LoRA nowhere
     used_by_rank = [{"expert_adaptor", "VETokenizer"}, {"expert_adaptor", "VEInstructor"}, {"expert_adaptor"},
-                    {"expert_adaptor", "VETokenizer"}]
+                    {"expert_adaptor", "VETokenizer"}] + [{"expert_adaptor"}] * (world - 4)
     for mode in ("allreduce", "rs_ag"):
         st = ParamStore(specs, "cpu")
         assert st.total % 32 == 0 and st.total >= st.n_used       # padded once: every shard of 2 / 4 / 8 ranks tiles it exactly
@@ -274,11 +274,11 @@ def _dp_world4_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_exchange_world4_gloo_with_ragged_module_use():
-    """Four ranks, each with its own prompt stage: the per-module use flags are summed by the same exchange that sums the
-    gradients (all-reduce) or ride beside it (reduce-scatter + all-gather); the padded flat buffer needs no per-step
-    concatenation, and the staging buffers of `rs_ag` are allocated once."""
-    world = 4
+@pytest.mark.parametrize("world", [4, 8])
+def test_exchange_world4_gloo_with_ragged_module_use(world):
+    """Four ranks -- and eight, the rank count of BASELINE configs[2] --, each with its own prompt stage: the per-module use
+    flags are summed by the same exchange that sums the gradients (all-reduce) or ride beside it (reduce-scatter + all-gather);
+    the padded flat buffer needs no per-step concatenation, and the staging buffers of `rs_ag` are allocated once."""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
@@ -293,7 +293,8 @@ def test_exchange_world4_gloo_with_ragged_module_use():
         mine = [torch.from_numpy(got[r][mode][0]) for r in range(world)]
         total = sum(mine)
         modules = got[0][mode][6]
-        want_flags = [4.0 if m == "expert_adaptor" else 2.0 if m == "VETokenizer" else 1.0 if m == "VEInstructor" else 0.0 for m in modules]
+        want_flags = [float(world) if m == "expert_adaptor" else 2.0 if m == "VETokenizer" else 1.0 if m == "VEInstructor" else 0.0
+                      for m in modules]
         for r in range(world):
             _, red, used, p, (lo, hi), n_new, _ = got[r][mode]
             red, p = torch.from_numpy(red), torch.from_numpy(p)

@@ -248,14 +248,19 @@ __global__ __launch_bounds__(256) void gemm_x4_kernel(const bf16_t* __restrict__
     // per-lane byte offsets of this wave's requests: request i stages rows (wave + 4 i) * 8 + (lane >> 3), the lane brings
     // the logical chunk that belongs at physical position lane & 7 (rows past the edge re-read the last row: never stored)
     int8v_t voa, vob;
+    // Rows past M / N: one row past the end lies outside the descriptor's range (num_records = rows * ld * 2; the scalar k offset
+    // is not part of the range check) and reads as ZERO instead of a copy of the last row.  Same results (those rows are never
+    // stored), but the MFMAs of the padding multiply zeros: the chip is power-limited under this loop, and 96 of the 1280 padded
+    // LLaMA rows doing no switching is worth 1.5-2.3 % on the M = 1184 launches (profiles/r04_gemm_x4.md).
+    const int zp = (flags & 0x20000000) ? 1 : 0;
     const int swz = (4 * (wave & 1) + (lane >> 4)) & 7;
     const int ch = ((lane & 7) ^ swz) << 4;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       const int row = (wave + 4 * i) * 8 + (lane >> 3);
       int ra = m0 + row, rb = n0 + row;
-      ra = ra < M ? ra : M - 1;
-      rb = rb < N ? rb : N - 1;
+      ra = ra < M ? ra : M - 1 + zp;               // zp: one row past the end = outside the descriptor's range: reads as zero
+      rb = rb < N ? rb : N - 1 + zp;
       voa[i] = ra * lda * 2 + ch;
       vob[i] = rb * ldb * 2 + ch;
     }
@@ -268,11 +273,11 @@ __global__ __launch_bounds__(256) void gemm_x4_kernel(const bf16_t* __restrict__
     int4v_t sa, sb;
     sa[0] = (int)(unsigned)(uintptr_t)A;
     sa[1] = (int)((unsigned)((uintptr_t)A >> 32) & 0xffffu);
-    sa[2] = -1;
+    sa[2] = zp ? (int)((unsigned)M * (unsigned)lda * 2u) : -1;
     sa[3] = 0x00020000;
     sb[0] = (int)(unsigned)(uintptr_t)B;
     sb[1] = (int)((unsigned)((uintptr_t)B >> 32) & 0xffffu);
-    sb[2] = -1;
+    sb[2] = zp ? (int)((unsigned)N * (unsigned)ldb * 2u) : -1;
     sb[3] = 0x00020000;
     unsigned koff = (unsigned)kt0 * 128u, cnt = (unsigned)nt, wr = sbase + wave * 1024;
     X4_DISPATCH4(V);
@@ -359,6 +364,11 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__
   {
     // request i of wave w stages rows (w + 8 i) * 8 + (lane >> 3); the swizzle term is again independent of i
     int4v_t voa, vob;
+    // Rows past M / N: one row past the end lies outside the descriptor's range (num_records = rows * ld * 2; the scalar k offset
+    // is not part of the range check) and reads as ZERO instead of a copy of the last row.  Same results (those rows are never
+    // stored), but the MFMAs of the padding multiply zeros: the chip is power-limited under this loop, and 96 of the 1280 padded
+    // LLaMA rows doing no switching is worth 1.5-2.3 % on the M = 1184 launches (profiles/r04_gemm_x4.md).
+    const int zp = (flags & 0x20000000) ? 1 : 0;
     const int swz = (4 * (wave & 1) + (lane >> 4)) & 7;
     const int ch = ((lane & 7) ^ swz) << 4;
 #if X4_NVARIANTS > 1
@@ -370,8 +380,8 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__
     for (int i = 0; i < 4; ++i) {
       const int row = (wave + 8 * i) * 8 + (lane >> 3);
       int ra = m0l + row, rb = n0l + row;
-      ra = ra < M ? ra : M - 1;
-      rb = rb < N ? rb : N - 1;
+      ra = ra < M ? ra : M - 1 + zp;               // zp: one row past the end = outside the descriptor's range: reads as zero
+      rb = rb < N ? rb : N - 1 + zp;
       voa[i] = ra * lda * 2 + ch;
       vob[i] = rb * ldb * 2 + ch;
     }
@@ -384,11 +394,11 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__
     int4v_t sa, sb;
     sa[0] = (int)(unsigned)(uintptr_t)A;
     sa[1] = (int)((unsigned)((uintptr_t)A >> 32) & 0xffffu);
-    sa[2] = -1;
+    sa[2] = zp ? (int)((unsigned)M * (unsigned)lda * 2u) : -1;
     sa[3] = 0x00020000;
     sb[0] = (int)(unsigned)(uintptr_t)B;
     sb[1] = (int)((unsigned)((uintptr_t)B >> 32) & 0xffffu);
-    sb[2] = -1;
+    sb[2] = zp ? (int)((unsigned)N * (unsigned)ldb * 2u) : -1;
     sb[3] = 0x00020000;
     unsigned koff = (unsigned)kt0 * 128u, cnt = (unsigned)nt, wr = sbase + wave * 1024;
     X4_DISPATCH8(V);
@@ -417,7 +427,8 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__
   }
 }
 
-static int x4_variant = 0, x4_same_panel = 0;
+static int x4_variant = 0, x4_same_panel = 0, x4_zero_pad = -1;
+extern "C" void mhdbg_set_gemm_x4_zero_pad(int on) { x4_zero_pad = on ? 1 : 0; }    // debug hook (tests, A/B): 0 = padding rows re-read the last row
 extern "C" void mhdbg_set_gemm_x4_same_panel(int on) { x4_same_panel = on; }                                   // sweep tool only
 extern "C" void mhdbg_set_gemm_x4_variant(int v) { x4_variant = (v >= 0 && v < X4_NVARIANTS) ? v : 0; }   // sweep tool only
 extern "C" int mhdbg_gemm_x4_nvariants() { return X4_NVARIANTS; }
@@ -436,6 +447,8 @@ int mh_launch_gemm_x4(const void* A, int lda, const void* B, int ldb, void* C, i
   const size_t shmem = 2 * X4_BUF;   // 128 KiB -> one 4-wave workgroup per CU
   const dim3 grid(tiles_m * tiles_n, splits);
   if (x4_same_panel) flags |= 0x40000000;
+  if (x4_zero_pad < 0) { const char* e = getenv("MYRIAD_GEMM_ZERO_PAD"); x4_zero_pad = (e && e[0] == '0') ? 0 : 1; }
+  if (x4_zero_pad) flags |= 0x20000000;
   if (g_mh_prof_on) mh_prof_pre(stream, 2, M, N, K, splits, flags);
 #define X4_LAUNCH(V)                                                                                                           \
   {                                                                                                                            \

@@ -177,6 +177,30 @@ def test_four_wave_and_eight_wave_instances_of_the_256_tile_are_bit_identical(M,
     assert torch.equal(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("M,N,K,pad", [(1184, 4160, 256, 0), (1184, 4160, 256, 64), (300, 520, 192, 8), (257, 256, 64, 0), (2056, 1408, 128, 0)])
+def test_padding_rows_of_the_256_tile_read_zeros_and_change_nothing(M, N, K, pad):
+    """The 256 x 256 kernel reads the rows past M / N as zeros (one row past the end lies outside the buffer descriptor's range)
+    instead of copies of the last row -- the padding MFMAs then switch nothing on a power-limited chip.  Same bits as with the
+    copies (mhdbg_set_gemm_x4_zero_pad(0)), for row strides wider than K and for operands that end exactly at their allocation."""
+    import ctypes
+    from myriad_amd import _lib as L
+    hook = ctypes.CDLL(L.LIB_PATH).mhdbg_set_gemm_x4_zero_pad
+    ops.ensure_workspace(torch.device(DEV))
+    a = bf(rnd(M, K + pad, seed=231)).to(DEV)[:, :K]                 # lda = K + pad; the last row ends `pad` elements before the allocation does
+    b = bf(rnd(N, K + pad, seed=232) * 0.05).to(DEV)[:, :K]
+    bias = rnd(N, seed=233).to(DEV)
+    outs = []
+    try:
+        for zp in (1, 0):
+            hook(zp)
+            outs.append((ops.gemm(a, b, bias=bias, variant=12), ops.gemm(a, b, out_dtype=torch.float32, variant=12)))
+    finally:
+        hook(1)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert relerr(outs[0][1], a.float() @ b.float().T) < 6e-3
+    assert not torch.isnan(outs[0][1]).any()
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 12288, 4160), (16, 1000, 11008), (3, 32000, 4096)])
 def test_skinny_m_weight_streaming_gemm(M, N, K):
     """M <= 16 routes to the decode weight-streaming kernel (gemv.hip)."""

@@ -341,6 +341,10 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
+  // debug (mhdbg_set_gemm_x4_clock_probe): shader-clock and 100-MHz stamps around this workgroup -> the clock the loop really ran at
+  const bool probe = flags & 0x10000000;
+  long long pc0 = 0, pr0 = 0;
+  if (probe) { pc0 = (long long)__builtin_amdgcn_s_memtime(); pr0 = (long long)__builtin_amdgcn_s_memrealtime(); }
   const int lr = lane & 15, lg = lane >> 4;
 
   const int nwg = gridDim.x, bid = blockIdx.x;
@@ -423,11 +427,18 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__
     else X8_WRITE(X8_WR_1);
     // SwiGLU: wave (wm, wn) holds gate columns for wn < 2 and pairs with (wm, wn + 2), as in gemm_256.hip
     x_readout(smem, ep, lane, m0 + wm * 128 + h * 64, wn, n0, wm * 4 + (wn & 1), 2, wn >> 1, wn & 1, Cv, bias, res, M, N, ldc, ldr,
-              flags, alpha, aux, ldaux);
+              flags, alpha, probe ? nullptr : aux, ldaux);
+  }
+  if (probe && tid == 0 && (blockIdx.x & 63) == 0 && blockIdx.y == 0) {
+    long long* o = reinterpret_cast<long long*>(aux) + (blockIdx.x >> 6) * 2;
+    o[0] = (long long)__builtin_amdgcn_s_memtime() - pc0;
+    o[1] = (long long)__builtin_amdgcn_s_memrealtime() - pr0;
   }
 }
 
 static int x4_variant = 0, x4_same_panel = 0, x4_zero_pad = -1;
+static void* x4_clock_probe = nullptr;
+extern "C" void mhdbg_set_gemm_x4_clock_probe(void* p) { x4_clock_probe = p; }   // debug: [8][2] int64 (shader cycles, 100-MHz ticks) of workgroups 0, 64, ..
 extern "C" void mhdbg_set_gemm_x4_zero_pad(int on) { x4_zero_pad = on ? 1 : 0; }    // debug hook (tests, A/B): 0 = padding rows re-read the last row
 extern "C" void mhdbg_set_gemm_x4_same_panel(int on) { x4_same_panel = on; }                                   // sweep tool only
 extern "C" void mhdbg_set_gemm_x4_variant(int v) { x4_variant = (v >= 0 && v < X4_NVARIANTS) ? v : 0; }   // sweep tool only
@@ -449,6 +460,7 @@ int mh_launch_gemm_x4(const void* A, int lda, const void* B, int ldb, void* C, i
   if (x4_same_panel) flags |= 0x40000000;
   if (x4_zero_pad < 0) { const char* e = getenv("MYRIAD_GEMM_ZERO_PAD"); x4_zero_pad = (e && e[0] == '0') ? 0 : 1; }
   if (x4_zero_pad) flags |= 0x20000000;
+  if (x4_clock_probe && !aux && !(flags & (MH_GEMM_SWIGLU_FWD | MH_GEMM_SWIGLU_BWD))) { flags |= 0x10000000; aux = x4_clock_probe; }
   if (g_mh_prof_on) mh_prof_pre(stream, 2, M, N, K, splits, flags);
 #define X4_LAUNCH(V)                                                                                                           \
   {                                                                                                                            \

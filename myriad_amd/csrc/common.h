@@ -38,16 +38,27 @@ void mh_prof_post(hipStream_t s);
 
 __device__ __forceinline__ float bf2f(bf16_t h) { return __uint_as_float(((unsigned)h) << 16); }
 
-// round-to-nearest-even fp32 -> bf16 (NaN stays NaN)
-__device__ __forceinline__ bf16_t f2bf(float f) {
+// round-to-nearest-even fp32 -> bf16.  gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, two elements per instruction);
+// the integer form (add 0x7fff + lsb, shift: ~8 VALU instructions per element) made every bf16 epilogue instruction-bound -- the
+// 256 x 256 GEMM's read-out of 128 outputs per lane took 7 us of its workgroup's time (profiles/r04_gemm_x4.md).  Same bits for
+// every finite input incl. denormals and ties (tests/test_kernels_gpu.py::test_bf16_rounding_in_hardware_equals_the_integer_form);
+// a NaN stays a quiet NaN.  f2bf_sw keeps the integer form for that test.
+typedef __bf16 mh_bf2_t __attribute__((ext_vector_type(2)));
+typedef float mh_f2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bf16_t f2bf_sw(float f) {
   unsigned u = __float_as_uint(f);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (bf16_t)(u >> 16);
 }
-
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  const __bf16 b = (__bf16)f;
+  return (bf16_t)__builtin_bit_cast(unsigned short, b);
+}
 __device__ __forceinline__ unsigned pack_bf2(float lo, float hi) {
-  return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16);
+  const mh_f2_t v = {lo, hi};
+  const mh_bf2_t b = __builtin_convertvector(v, mh_bf2_t);
+  return __builtin_bit_cast(unsigned, b);
 }
 
 // Counter-based dropout keep-mask (PEFT lora_dropout, reference myriad.py:171-178): a pure function of (seed, flat

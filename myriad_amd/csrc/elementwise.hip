@@ -644,3 +644,25 @@ extern "C" int mh_add_i32(int* x, int n, int delta, hipStream_t stream) {
   MH_CHECK_LAUNCH();
   return MH_OK;
 }
+
+// debug (tests): the hardware fp32 -> bf16 rounding next to the integer form it replaced (common.h), element by element
+__global__ void bf16_round_check_kernel(const float* __restrict__ x, bf16_t* __restrict__ hw, bf16_t* __restrict__ hw_pk,
+                                        bf16_t* __restrict__ sw, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (2 * i + 1 >= n) return;
+  const float a = x[2 * i], b = x[2 * i + 1];
+  hw[2 * i] = f2bf(a);
+  hw[2 * i + 1] = f2bf(b);
+  const unsigned pk = pack_bf2(a, b);
+  hw_pk[2 * i] = (bf16_t)(pk & 0xffffu);
+  hw_pk[2 * i + 1] = (bf16_t)(pk >> 16);
+  sw[2 * i] = f2bf_sw(a);
+  sw[2 * i + 1] = f2bf_sw(b);
+}
+extern "C" int mhdbg_bf16_round_check(const float* x, void* hw, void* hw_pk, void* sw, long n, hipStream_t stream) {
+  if (n <= 0 || (n & 1)) return MH_ERR_ARG;
+  hipLaunchKernelGGL(bf16_round_check_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, stream, x, (bf16_t*)hw,
+                     (bf16_t*)hw_pk, (bf16_t*)sw, n);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}

@@ -126,6 +126,73 @@ __device__ __forceinline__ void x_readout(char* smem, char* ep, int lane, int mb
   if (!out_f32 && (ldc & 7) == 0) {
     const int r8 = lane >> 3, c8 = lane & 7;
     const int nc = n0 + wc * 64 + c8 * 8;
+    // Interior block (all 64 x 64 outputs inside M x N): the options are tested once, the bias of the lane's eight columns is
+    // loaded once, the row address advances by a constant -- per 8 rows two LDS reads, the epilogue arithmetic, four packed
+    // conversions and one full-line store.  The generic loop below (edges) re-tests everything and redoes a 64-bit address per
+    // row; with 128 outputs per lane and two waves per SIMD the read-out is instruction-bound (7.3 us of a workgroup's time with
+    // the integer bf16 rounding, 2.5 us now: profiles/r04_gemm_x4.md).  Same expressions, same bits.
+    if (!sw_fwd && mbase + 63 < M && n0 + wc * 64 + 63 < N && !(flags & 0x08000000)) {
+      bf16_t* dst = reinterpret_cast<bf16_t*>(Cv) + (size_t)(mbase + r8) * ldc + nc;
+      const size_t step = (size_t)8 * ldc;
+      const char* e0 = ep + r8 * 256;
+      const bool plain = !bias && !do_gelu && !res && alpha == 1.0f;
+      if (plain) {
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+          const int sw = ((p & 1) * 8 + r8) & 15;          // row & 15 for row = p * 8 + r8
+          const float4_t va = *reinterpret_cast<const float4_t*>(e0 + p * 2048 + (((2 * c8) ^ sw) << 4));
+          const float4_t vb = *reinterpret_cast<const float4_t*>(e0 + p * 2048 + (((2 * c8 + 1) ^ sw) << 4));
+          uint4 pk;
+          pk.x = pack_bf2(va[0], va[1]);
+          pk.y = pack_bf2(va[2], va[3]);
+          pk.z = pack_bf2(vb[0], vb[1]);
+          pk.w = pack_bf2(vb[2], vb[3]);
+          *reinterpret_cast<uint4*>(dst) = pk;
+          dst += step;
+        }
+        return;
+      }
+      float bb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (bias) {
+        const float4_t b0 = *reinterpret_cast<const float4_t*>(bias + nc);
+        const float4_t b1 = *reinterpret_cast<const float4_t*>(bias + nc + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { bb[e] = b0[e]; bb[4 + e] = b1[e]; }
+      }
+      const float* rp = res ? res + (size_t)(mbase + r8) * ldr + nc : nullptr;
+      const size_t rstep = (size_t)8 * ldr;
+#pragma unroll 2
+      for (int p = 0; p < 8; ++p) {
+        const int sw = ((p & 1) * 8 + r8) & 15;
+        const float4_t va = *reinterpret_cast<const float4_t*>(e0 + p * 2048 + (((2 * c8) ^ sw) << 4));
+        const float4_t vb = *reinterpret_cast<const float4_t*>(e0 + p * 2048 + (((2 * c8 + 1) ^ sw) << 4));
+        float v[8] = {va[0] * alpha, va[1] * alpha, va[2] * alpha, va[3] * alpha,
+                      vb[0] * alpha, vb[1] * alpha, vb[2] * alpha, vb[3] * alpha};
+        if (bias) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] += bb[e];
+        }
+        if (do_gelu) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
+        }
+        if (rp) {
+          const float4_t q0 = *reinterpret_cast<const float4_t*>(rp);
+          const float4_t q1 = *reinterpret_cast<const float4_t*>(rp + 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) { v[e] += q0[e]; v[4 + e] += q1[e]; }
+          rp += rstep;
+        }
+        uint4 pk;
+        pk.x = pack_bf2(v[0], v[1]);
+        pk.y = pack_bf2(v[2], v[3]);
+        pk.z = pack_bf2(v[4], v[5]);
+        pk.w = pack_bf2(v[6], v[7]);
+        *reinterpret_cast<uint4*>(dst) = pk;
+        dst += step;
+      }
+      return;
+    }
 #pragma unroll 4
     for (int p = 0; p < 8; ++p) {
       const int row = p * 8 + r8;
@@ -157,6 +224,7 @@ __device__ __forceinline__ void x_readout(char* smem, char* ep, int lane, int mb
         pk.y = pack_bf2(v[2], v[3]);
         pk.z = pack_bf2(v[4], v[5]);
         pk.w = pack_bf2(v[6], v[7]);
+        if (flags & 0x08000000) { if (pk.x == 0x12345678u) reinterpret_cast<unsigned*>(Cv)[0] = pk.y ^ pk.z ^ pk.w; continue; }   // TIMING PROBE: no stores
         *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(Cv) + (size_t)m * ldc + nc) = pk;
       } else {
         for (int e = 0; e < 8 && nc + e < N; ++e) {
@@ -343,7 +411,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__
   const int wm = wave >> 2, wn = wave & 3;
   // debug (mhdbg_set_gemm_x4_clock_probe): shader-clock and 100-MHz stamps around this workgroup -> the clock the loop really ran at
   const bool probe = flags & 0x10000000;
-  long long pc0 = 0, pr0 = 0;
+  long long pc0 = 0, pr0 = 0, pr1 = 0, pr2 = 0;
   if (probe) { pc0 = (long long)__builtin_amdgcn_s_memtime(); pr0 = (long long)__builtin_amdgcn_s_memrealtime(); }
   const int lr = lane & 15, lg = lane >> 4;
 
@@ -405,7 +473,9 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__
     sb[2] = zp ? (int)((unsigned)N * (unsigned)ldb * 2u) : -1;
     sb[3] = 0x00020000;
     unsigned koff = (unsigned)kt0 * 128u, cnt = (unsigned)nt, wr = sbase + wave * 1024;
+    if (probe) pr1 = (long long)__builtin_amdgcn_s_memrealtime();
     X4_DISPATCH8(V);
+    if (probe) pr2 = (long long)__builtin_amdgcn_s_memrealtime();
   }
 
   char* ep = smem + wave * 16384;
@@ -430,15 +500,19 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__
               flags, alpha, probe ? nullptr : aux, ldaux);
   }
   if (probe && tid == 0 && (blockIdx.x & 63) == 0 && blockIdx.y == 0) {
-    long long* o = reinterpret_cast<long long*>(aux) + (blockIdx.x >> 6) * 2;
+    long long* o = reinterpret_cast<long long*>(aux) + (blockIdx.x >> 6) * 4;
     o[0] = (long long)__builtin_amdgcn_s_memtime() - pc0;
     o[1] = (long long)__builtin_amdgcn_s_memrealtime() - pr0;
+    o[2] = pr1 - pr0;                                  // entry -> first request (index math, descriptors)
+    o[3] = pr2 - pr0;                                  // entry -> end of the K loop
   }
 }
 
 static int x4_variant = 0, x4_same_panel = 0, x4_zero_pad = -1;
 static void* x4_clock_probe = nullptr;
-extern "C" void mhdbg_set_gemm_x4_clock_probe(void* p) { x4_clock_probe = p; }   // debug: [8][2] int64 (shader cycles, 100-MHz ticks) of workgroups 0, 64, ..
+static int x4_no_stores = 0;
+extern "C" void mhdbg_set_gemm_x4_no_stores(int on) { x4_no_stores = on; }   // TIMING PROBE
+extern "C" void mhdbg_set_gemm_x4_clock_probe(void* p) { x4_clock_probe = p; }   // debug: [8][4] int64 (shader cycles, 100-MHz ticks total / to the loop / to the loop's end) of workgroups 0, 64, ..
 extern "C" void mhdbg_set_gemm_x4_zero_pad(int on) { x4_zero_pad = on ? 1 : 0; }    // debug hook (tests, A/B): 0 = padding rows re-read the last row
 extern "C" void mhdbg_set_gemm_x4_same_panel(int on) { x4_same_panel = on; }                                   // sweep tool only
 extern "C" void mhdbg_set_gemm_x4_variant(int v) { x4_variant = (v >= 0 && v < X4_NVARIANTS) ? v : 0; }   // sweep tool only
@@ -460,6 +534,7 @@ int mh_launch_gemm_x4(const void* A, int lda, const void* B, int ldb, void* C, i
   if (x4_same_panel) flags |= 0x40000000;
   if (x4_zero_pad < 0) { const char* e = getenv("MYRIAD_GEMM_ZERO_PAD"); x4_zero_pad = (e && e[0] == '0') ? 0 : 1; }
   if (x4_zero_pad) flags |= 0x20000000;
+  if (x4_no_stores) flags |= 0x08000000;
   if (x4_clock_probe && !aux && !(flags & (MH_GEMM_SWIGLU_FWD | MH_GEMM_SWIGLU_BWD))) { flags |= 0x10000000; aux = x4_clock_probe; }
   if (g_mh_prof_on) mh_prof_pre(stream, 2, M, N, K, splits, flags);
 #define X4_LAUNCH(V)                                                                                                           \

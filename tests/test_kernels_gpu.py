@@ -177,6 +177,36 @@ def test_four_wave_and_eight_wave_instances_of_the_256_tile_are_bit_identical(M,
     assert torch.equal(outs[0], outs[1])
 
 
+def test_bf16_rounding_in_hardware_equals_the_integer_form():
+    """common.h rounds fp32 -> bf16 with gfx950's v_cvt_pk_bf16_f32 (scalar and packed forms) instead of the integer
+    add-0x7fff-plus-lsb sequence: the same bits for every high half (all 65536) combined with the low halves that decide a
+    rounding (ties, one below / above, zero, all ones) -- finite values, denormals, the overflow to infinity -- and a quiet NaN
+    for a NaN."""
+    import ctypes
+    from myriad_amd import _lib as L
+    lib = ctypes.CDLL(L.LIB_PATH)
+    fn = lib.mhdbg_bf16_round_check
+    fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_long, ctypes.c_void_p]
+    fn.restype = ctypes.c_int
+    hi = torch.arange(65536, dtype=torch.int64)
+    lows = torch.tensor([0x0000, 0x0001, 0x7fff, 0x8000, 0x8001, 0xffff, 0x1234, 0xfedc], dtype=torch.int64)
+    bits = ((hi[:, None] << 16) | lows[None, :]).reshape(-1)
+    g = torch.Generator().manual_seed(5)
+    bits = torch.cat([bits, torch.randint(0, 2 ** 32, (1 << 20,), generator=g, dtype=torch.int64)])
+    x = bits.to(torch.int32, copy=True) if False else (bits & 0xffffffff)
+    x = torch.where(x >= 2 ** 31, x - 2 ** 32, x).to(torch.int32).view(torch.float32).to(DEV)
+    n = x.numel()
+    outs = [torch.empty(n, dtype=torch.int16, device=DEV) for _ in range(3)]
+    assert fn(x.data_ptr(), outs[0].data_ptr(), outs[1].data_ptr(), outs[2].data_ptr(), n, torch.cuda.current_stream().cuda_stream) == 0
+    hw, hw_pk, sw = (o.cpu().to(torch.int64) & 0xffff for o in outs)
+    nan = torch.isnan(x.cpu())
+    assert torch.equal(hw[~nan], sw[~nan]) and torch.equal(hw_pk[~nan], sw[~nan])
+    for t in (hw, hw_pk, sw):                              # a NaN stays a (quiet) NaN, sign kept
+        tn = t[nan]
+        assert bool(((tn & 0x7f80) == 0x7f80).all()) and bool(((tn & 0x007f) != 0).all())
+    assert int(nan.sum()) > 1000 and int((~nan).sum()) > 1_000_000
+
+
 @pytest.mark.parametrize("M,N,K,pad", [(1184, 4160, 256, 0), (1184, 4160, 256, 64), (300, 520, 192, 8), (257, 256, 64, 0), (2056, 1408, 128, 0)])
 def test_padding_rows_of_the_256_tile_read_zeros_and_change_nothing(M, N, K, pad):
     """The 256 x 256 kernel reads the rows past M / N as zeros (one row past the end lies outside the buffer descriptor's range)

@@ -26,7 +26,7 @@ for (M, N, K) in ((256, 256, 16384), (2048, 2048, 8192), (2048, 4096, 8192), (40
         ops.gemm(a, b, out=out, variant=12)
     torch.cuda.synchronize()
     L.mhdbg_set_gemm_x4_clock_probe(None)
-    p = probe.cpu().view(-1, 2)
+    p = probe.cpu().view(-1, 4)[:, :2]
     tiles = ((M + 255) // 256) * ((N + 255) // 256)
     rows = [(int(c), int(t)) for c, t in p.tolist() if t > 0]
     ghz = [c / t * 0.1 for c, t in rows]
@@ -37,7 +37,8 @@ for (M, N, K) in ((256, 256, 16384), (2048, 2048, 8192), (2048, 4096, 8192), (40
 # in-workgroup time vs launch-to-launch time: what a launch costs OUTSIDE its workgroups (dispatch, end-of-kernel L2 write-back
 # across the eight XCDs, next launch)
 print("\n| shape | K | launch-to-launch us | probed workgroups us (min-max) | outside the workgroups us | GHz |\n|---|---|---|---|---|---|")
-for (M, N) in ((4096, 4096), (1184, 12288), (2056, 6144)):
+for (M, N, NOST) in ((4096, 4096, 0), (4096, 4096, 1), (1184, 12288, 0), (2056, 6144, 0)):
+    L.mhdbg_set_gemm_x4_no_stores(NOST)
     for K in (64, 256, 1024, 4096):
         a = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
         b = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
@@ -57,7 +58,11 @@ for (M, N) in ((4096, 4096), (1184, 12288), (2056, 6144)):
             ops.gemm(a, b, out=out, variant=12)
         torch.cuda.synchronize()
         L.mhdbg_set_gemm_x4_clock_probe(None)
-        rows = [(int(c), int(t)) for c, t in probe.cpu().view(-1, 2).tolist() if t > 0]
-        us = [t / 100 for _, t in rows]
-        ghz = sum(c / t * 0.1 for c, t in rows) / len(rows)
-        print(f"| {M}x{N} | {K} | {l2l:.1f} | {min(us):.1f}-{max(us):.1f} | {l2l - max(us):.1f} | {ghz:.2f} |", flush=True)
+        rows = [(int(c), int(t), int(h), int(e)) for c, t, h, e in probe.cpu().view(-1, 4).tolist() if t > 0]
+        us = [t / 100 for _, t, _, _ in rows]
+        ghz = sum(c / t * 0.1 for c, t, _, _ in rows) / len(rows)
+        head = sum(h for _, _, h, _ in rows) / len(rows) / 100
+        loop = sum(e - h for _, _, h, e in rows) / len(rows) / 100
+        tail = sum(t - e for _, t, _, e in rows) / len(rows) / 100
+        print(f"| {M}x{N}{' NO STORES' if NOST else ''} | {K} | {l2l:.1f} | {min(us):.1f}-{max(us):.1f} (setup {head:.2f} + loop {loop:.1f} + read-out {tail:.1f}) | {l2l - max(us):.1f} | {ghz:.2f} |", flush=True)
+L.mhdbg_set_gemm_x4_no_stores(0)

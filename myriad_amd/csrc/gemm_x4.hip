@@ -126,12 +126,14 @@ __device__ __forceinline__ void x_readout(char* smem, char* ep, int lane, int mb
   if (!out_f32 && (ldc & 7) == 0) {
     const int r8 = lane >> 3, c8 = lane & 7;
     const int nc = n0 + wc * 64 + c8 * 8;
-    // Interior block (all 64 x 64 outputs inside M x N): the options are tested once, the bias of the lane's eight columns is
+    // Block whose 64 columns lie inside N (rows past M are skipped row by row): the options are tested once, the bias of the lane's eight columns is
     // loaded once, the row address advances by a constant -- per 8 rows two LDS reads, the epilogue arithmetic, four packed
     // conversions and one full-line store.  The generic loop below (edges) re-tests everything and redoes a 64-bit address per
     // row; with 128 outputs per lane and two waves per SIMD the read-out is instruction-bound (7.3 us of a workgroup's time with
     // the integer bf16 rounding, 2.5 us now: profiles/r04_gemm_x4.md).  Same expressions, same bits.
-    if (!sw_fwd && mbase + 63 < M && n0 + wc * 64 + 63 < N && !(flags & 0x08000000)) {
+    if (!sw_fwd && (mbase >= M || n0 + wc * 64 >= N)) return;        // the block lies in the padding: nothing to store
+    if (!sw_fwd && n0 + wc * 64 + 63 < N && !(flags & 0x08000000)) {
+      const int mrows = M - mbase - r8;                               // row p * 8 + r8 of the block is stored iff p * 8 < mrows
       bf16_t* dst = reinterpret_cast<bf16_t*>(Cv) + (size_t)(mbase + r8) * ldc + nc;
       const size_t step = (size_t)8 * ldc;
       const char* e0 = ep + r8 * 256;
@@ -147,7 +149,7 @@ __device__ __forceinline__ void x_readout(char* smem, char* ep, int lane, int mb
           pk.y = pack_bf2(va[2], va[3]);
           pk.z = pack_bf2(vb[0], vb[1]);
           pk.w = pack_bf2(vb[2], vb[3]);
-          *reinterpret_cast<uint4*>(dst) = pk;
+          if (p * 8 < mrows) *reinterpret_cast<uint4*>(dst) = pk;
           dst += step;
         }
         return;
@@ -177,10 +179,12 @@ __device__ __forceinline__ void x_readout(char* smem, char* ep, int lane, int mb
           for (int e = 0; e < 8; ++e) v[e] = gelu_erf(v[e]);
         }
         if (rp) {
-          const float4_t q0 = *reinterpret_cast<const float4_t*>(rp);
-          const float4_t q1 = *reinterpret_cast<const float4_t*>(rp + 4);
+          if (p * 8 < mrows) {
+            const float4_t q0 = *reinterpret_cast<const float4_t*>(rp);
+            const float4_t q1 = *reinterpret_cast<const float4_t*>(rp + 4);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) { v[e] += q0[e]; v[4 + e] += q1[e]; }
+            for (int e = 0; e < 4; ++e) { v[e] += q0[e]; v[4 + e] += q1[e]; }
+          }
           rp += rstep;
         }
         uint4 pk;
@@ -188,7 +192,7 @@ __device__ __forceinline__ void x_readout(char* smem, char* ep, int lane, int mb
         pk.y = pack_bf2(v[2], v[3]);
         pk.z = pack_bf2(v[4], v[5]);
         pk.w = pack_bf2(v[6], v[7]);
-        *reinterpret_cast<uint4*>(dst) = pk;
+        if (p * 8 < mrows) *reinterpret_cast<uint4*>(dst) = pk;
         dst += step;
       }
       return;

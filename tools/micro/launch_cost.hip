@@ -36,5 +36,25 @@ int main() {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("256 threads, no LDS, grid %4d: %.2f us per back-to-back launch\n", g, ms * 1e3 / n);
   }
+  // the same chain of launches replayed from a hipGraph (stream capture): does a graph shorten the launch-to-launch time of
+  // DEPENDENT kernels?
+  for (int lds : {131072, 0}) for (int g : {240, 256}) {
+    const int n = 400;
+    hipGraph_t graph; hipGraphExec_t exec;
+    hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal);
+    for (int i = 0; i < n; ++i) {
+      if (lds) hipLaunchKernelGGL(k, dim3(g), dim3(512), lds, s, (float*)nullptr);
+      else hipLaunchKernelGGL(k_small, dim3(g), dim3(256), 0, s, (float*)nullptr);
+    }
+    hipStreamEndCapture(s, &graph);
+    hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    hipGraphLaunch(exec, s); hipStreamSynchronize(s);
+    hipEventRecord(e0, s);
+    hipGraphLaunch(exec, s);
+    hipEventRecord(e1, s); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    printf("hipGraph of %d dependent launches, %s, grid %d: %.2f us per launch\n", n, lds ? "512 thr / 128 KiB LDS" : "256 thr / no LDS", g, ms * 1e3 / n);
+    hipGraphExecDestroy(exec); hipGraphDestroy(graph);
+  }
   return 0;
 }

@@ -874,10 +874,11 @@ extern "C" void mhdbg_set_swiglu_fused(int on) { g_swiglu_fused = on ? 1 : 0; } 
 static bool swiglu_fusable(int M, int N, int K, int lda, int ldb, const void* A, const void* B) {
   int kernel = 1, splits = 1;
   gemm_plan(M, N, K, 0, &kernel, &splits);
-  // Measured (round 2, batch-8 step, same box A/B): fused 52.21 ms, separate launches 51.98 ms -- the elementwise kernels
-  // already run at HBM rate on all 256 CUs, while the epilogue of a one-workgroup-per-CU GEMM is an un-overlapped tail, so
-  // the saved round trip of dact / gu is spent again in the tail.  Off by default; MYRIAD_SWIGLU_FUSED=1 selects it.
-  if (g_swiglu_fused < 0) { const char* e = getenv("MYRIAD_SWIGLU_FUSED"); g_swiglu_fused = (e && e[0] == '1') ? 1 : 0; }
+  // Measured, batch-8 step, same box A/B: round 2 fused 52.21 ms vs separate launches 51.98; round 4 (eight-wave loop) 44.8 vs 44.8 --
+  // the read-out of a one-workgroup-per-CU GEMM was instruction-bound (integer bf16 rounding), so the elementwise work added
+  // to it cost what the saved launch and round trip of dact / gu gave back.  With the hardware rounding the fused forms win:
+  // 42.20 / 42.20 ms against 42.34 / 42.41 (late round 4).  On by default; MYRIAD_SWIGLU_FUSED=0 runs the separate launches.
+  if (g_swiglu_fused < 0) { const char* e = getenv("MYRIAD_SWIGLU_FUSED"); g_swiglu_fused = (e && e[0] == '0') ? 0 : 1; }
   return g_swiglu_fused && kernel == 2 && splits == 1 && (N % 128) == 0 && (K % 64) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 &&
          !(((uintptr_t)A | (uintptr_t)B) & 15);
 }

@@ -494,7 +494,8 @@ def test_attention_online_softmax_spike():
 def test_swiglu_fused_into_the_mlp_gemms(M, I, K):
     """mh_gemm_swiglu_fwd/bwd (SiLU-gated product in the gate|up GEMM's epilogue, its backward in the down dgrad's) against
     an fp32 torch model of LlamaMLP (modeling_llama.py:139-140) and bit-for-bit against GEMM + silu kernels.  The fused
-    epilogues are opt-in (MYRIAD_SWIGLU_FUSED=1: measured at parity with the separate launches); the debug hook selects them."""
+    epilogues are the default since the read-out rounds in hardware (MYRIAD_SWIGLU_FUSED=0: the separate launches); the debug
+    hook selects them explicitly."""
     import ctypes
     from myriad_amd import _lib as L
     hook = ctypes.CDLL(L.LIB_PATH).mhdbg_set_swiglu_fused
@@ -503,7 +504,7 @@ def test_swiglu_fused_into_the_mlp_gemms(M, I, K):
     try:
         _swiglu_case(M, I, K)
     finally:
-        hook(0)
+        hook(1)
 
 
 def _swiglu_case(M, I, K):

@@ -18,6 +18,11 @@ import os
 import sys
 import time
 
+# Kernel arguments in device memory: HIP's default places the kernarg segment in host memory, and every kernel begins by fetching
+# it over the host link -- 0.9 ms of a 42 ms step, 1.5 ms of the 20 ms batch-1 step (profiles/r04_gemm_x4.md).  Must be set before
+# the HIP runtime initialises (first device call); a value the user set is respected.
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))

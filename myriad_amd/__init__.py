@@ -3,4 +3,11 @@
 Python host code (this package) calls hand-written HIP kernels in libmyriad_hip.so through the C ABI declared in
 include/myriad_hip.h.  PyTorch supplies device memory, streams and torch.distributed (RCCL) only.
 """
+import os as _os
+
+# Kernel arguments in device memory: HIP's default places the kernarg segment in host memory, and every kernel begins by fetching
+# it over the host link -- 0.9 ms of a 42 ms step, 1.5 ms of the 20 ms batch-1 step (profiles/r04_gemm_x4.md).  Must be set before
+# the HIP runtime initialises (first device call); a value the user set is respected.
+_os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
+
 __version__ = "0.1.0"

@@ -122,7 +122,7 @@ class LaunchProfile:
     def subset(self, kid, pred):
         v = [0, 0.0, 0.0]
         for (k, M, N, K, sp, flags), ms in self.records:
-            if k == kid and pred(sp):
+            if k == kid and pred(sp, flags):
                 v[0] += 1; v[1] += ms; v[2] += 2.0 * M * N * K
         if not v[0]:
             return None
@@ -414,7 +414,12 @@ def main():
                                        "duration of an empty pair)",
                             launches_per_step=dk["launches"], avg_launch_us=dk["avg_us"], kernel_ms_per_step=dk["total_ms"],
                             event_pair_overhead_us=round(1e3 * lp.overhead_ms, 2),
-                            unsplit_launches=lp.subset(did, lambda sp: sp == 1), split_launches=lp.subset(did, lambda sp: sp > 1),
+                            unsplit_launches=lp.subset(did, lambda sp, fl: sp == 1), split_launches=lp.subset(did, lambda sp, fl: sp > 1),
+                            # launches whose read-out also does the SiLU gate of the MLP (forward: gate|up product, backward: the
+                            # down projection's dgrad; csrc/gemm.hip mh_gemm_swiglu_*) carry elementwise work the FLOP count
+                            # above does not credit: shown apart, counted in `achieved` / `frac` like every other launch
+                            launches_with_fused_gate=lp.subset(did, lambda sp, fl: bool(fl & 48)),
+                            launches_without_fused_gate=lp.subset(did, lambda sp, fl: not (fl & 48)),
                             per_kernel=per,
                             by_shape=[dict(kernel=KERNEL_NAMES.get(kid, kid), M=m, N=n, K=k, splits=sp, launches=cnt,
                                            total_ms=round(ms, 3), tflops=round(tf, 1))

@@ -70,8 +70,23 @@ __device__ __forceinline__ void x_readout(char* smem, char* ep, int lane, int mb
     const long gcol = (long)(nc >> 7) * 256 + (nc & 127);
     const bf16_t* gu_in = reinterpret_cast<const bf16_t*>(aux);
     bf16_t* dgu = reinterpret_cast<bf16_t*>(Cv);
-#pragma unroll 4
-    for (int p = 0; p < 8; ++p) {
+    // the gate / up values of four rows at a time, loaded before they are used (4 rows x 2 x 16 B per lane: the K loop's
+    // registers are free here): the loop waits for one memory round trip per four rows instead of one per row
+    for (int ph = 0; ph < 2; ++ph) {
+    short8_t gq[4], uq[4];
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int m = mbase + (ph * 4 + pp) * 8 + r8;
+      gq[pp] = (short8_t){0, 0, 0, 0, 0, 0, 0, 0};
+      uq[pp] = gq[pp];
+      if (m < M && nc < N) {
+        gq[pp] = *reinterpret_cast<const short8_t*>(gu_in + (size_t)m * ldaux + gcol);
+        uq[pp] = *reinterpret_cast<const short8_t*>(gu_in + (size_t)m * ldaux + gcol + 128);
+      }
+    }
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+      const int p = ph * 4 + pp;
       const int row = p * 8 + r8;
       const int m = mbase + row;
       const float4_t va = *reinterpret_cast<const float4_t*>(ep + row * 256 + (((2 * c8) ^ (row & 15)) << 4));
@@ -79,8 +94,8 @@ __device__ __forceinline__ void x_readout(char* smem, char* ep, int lane, int mb
       if (m >= M || nc >= N) continue;
       const float v[8] = {va[0] * alpha, va[1] * alpha, va[2] * alpha, va[3] * alpha,
                           vb[0] * alpha, vb[1] * alpha, vb[2] * alpha, vb[3] * alpha};
-      const short8_t g8 = *reinterpret_cast<const short8_t*>(gu_in + (size_t)m * ldaux + gcol);
-      const short8_t u8 = *reinterpret_cast<const short8_t*>(gu_in + (size_t)m * ldaux + gcol + 128);
+      const short8_t g8 = gq[pp];
+      const short8_t u8 = uq[pp];
       short8_t og, ou;
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
@@ -92,6 +107,7 @@ __device__ __forceinline__ void x_readout(char* smem, char* ep, int lane, int mb
       }
       *reinterpret_cast<short8_t*>(dgu + (size_t)m * ldc + gcol) = og;
       *reinterpret_cast<short8_t*>(dgu + (size_t)m * ldc + gcol + 128) = ou;
+    }
     }
     return;
   }

@@ -1,0 +1,26 @@
+import sys; sys.path.insert(0, "/root/repo")
+import torch
+from myriad_amd import ops, _lib
+L = _lib.load(); dev = torch.device("cuda:0"); ops.ensure_workspace(dev)
+M, N, K = 2056, 1408, 1408
+a = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
+ws = [(torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16) for _ in range(40)]
+bias = torch.randn(N, device=dev); h = torch.randn(M, N, device=dev); nw = torch.randn(N, device=dev); nb = torch.randn(N, device=dev)
+def t(fn, n=40):
+    for i in range(5): fn(i)
+    best = 1e9
+    for _ in range(4):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for i in range(n): fn(i)
+        e1.record(); torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / n * 1e3)
+    return best
+for plan in ((-1, 0), (2, 2), (2, 3), (2, 4), (2, 5), (3, 1), (1, 2), (1, 3)):
+    L.mhdbg_set_force_plan(plan[0], plan[1])
+    try:
+        us = t(lambda i: ops.gemm_residual_layernorm(a, ws[i % 40], bias, h.clone() if False else h, nw, nb, 1e-6))
+        print(plan, f"{us:.1f} us", ops.gemm_plan(M, N, K))
+    except Exception as e:
+        print(plan, "failed", str(e)[:80])
+L.mhdbg_set_force_plan(-1, 0)

@@ -28,6 +28,11 @@
 
 #define MH_GEMM_OUT_F32 1
 #define MH_GEMM_GELU 2
+// launcher-internal flag bits (never part of the ABI's flags): debug hooks of the sweep / probe tools and the padding policy
+#define X4_F_SAME_PANEL 0x40000000   // every workgroup stages tile (0, 0)'s panels (all-L2-hit timing probe; sweep builds)
+#define X4_F_ZERO_PAD 0x20000000     // rows past M / N read as zeros (default on; mhdbg_set_gemm_x4_zero_pad)
+#define X4_F_CLOCK_PROBE 0x10000000  // aux = int64 stamps of workgroups 0, 64, .. (mhdbg_set_gemm_x4_clock_probe)
+#define X4_F_NO_STORES 0x08000000    // read-out without its global stores (mhdbg_set_gemm_x4_no_stores: timing only, wrong results)
 #define MH_GEMM_SWIGLU_FWD 16
 #define MH_GEMM_SWIGLU_BWD 32
 
@@ -148,7 +153,7 @@ __device__ __forceinline__ void x_readout(char* smem, char* ep, int lane, int mb
     // row; with 128 outputs per lane and two waves per SIMD the read-out is instruction-bound (7.3 us of a workgroup's time with
     // the integer bf16 rounding, 2.5 us now: profiles/r04_gemm_x4.md).  Same expressions, same bits.
     if (!sw_fwd && (mbase >= M || n0 + wc * 64 >= N)) return;        // the block lies in the padding: nothing to store
-    if (!sw_fwd && n0 + wc * 64 + 63 < N && !(flags & 0x08000000)) {
+    if (!sw_fwd && n0 + wc * 64 + 63 < N && !(flags & X4_F_NO_STORES)) {
       const int mrows = M - mbase - r8;                               // row p * 8 + r8 of the block is stored iff p * 8 < mrows
       bf16_t* dst = reinterpret_cast<bf16_t*>(Cv) + (size_t)(mbase + r8) * ldc + nc;
       const size_t step = (size_t)8 * ldc;
@@ -244,7 +249,7 @@ __device__ __forceinline__ void x_readout(char* smem, char* ep, int lane, int mb
         pk.y = pack_bf2(v[2], v[3]);
         pk.z = pack_bf2(v[4], v[5]);
         pk.w = pack_bf2(v[6], v[7]);
-        if (flags & 0x08000000) { if (pk.x == 0x12345678u) reinterpret_cast<unsigned*>(Cv)[0] = pk.y ^ pk.z ^ pk.w; continue; }   // TIMING PROBE: no stores
+        if (flags & X4_F_NO_STORES) { if (pk.x == 0x12345678u) reinterpret_cast<unsigned*>(Cv)[0] = pk.y ^ pk.z ^ pk.w; continue; }   // timing probe (X4_F_NO_STORES)
         *reinterpret_cast<uint4*>(reinterpret_cast<bf16_t*>(Cv) + (size_t)m * ldc + nc) = pk;
       } else {
         for (int e = 0; e < 8 && nc + e < N; ++e) {
@@ -340,7 +345,7 @@ __global__ __launch_bounds__(256) void gemm_x4_kernel(const bf16_t* __restrict__
     // is not part of the range check) and reads as ZERO instead of a copy of the last row.  Same results (those rows are never
     // stored), but the MFMAs of the padding multiply zeros: the chip is power-limited under this loop, and 96 of the 1280 padded
     // LLaMA rows doing no switching is worth 1.5-2.3 % on the M = 1184 launches (profiles/r04_gemm_x4.md).
-    const int zp = (flags & 0x20000000) ? 1 : 0;
+    const int zp = (flags & X4_F_ZERO_PAD) ? 1 : 0;
     const int swz = (4 * (wave & 1) + (lane >> 4)) & 7;
     const int ch = ((lane & 7) ^ swz) << 4;
 #pragma unroll
@@ -430,7 +435,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
   // debug (mhdbg_set_gemm_x4_clock_probe): shader-clock and 100-MHz stamps around this workgroup -> the clock the loop really ran at
-  const bool probe = flags & 0x10000000;
+  const bool probe = flags & X4_F_CLOCK_PROBE;
   long long pc0 = 0, pr0 = 0, pr1 = 0, pr2 = 0;
   if (probe) { pc0 = (long long)__builtin_amdgcn_s_memtime(); pr0 = (long long)__builtin_amdgcn_s_memrealtime(); }
   const int lr = lane & 15, lg = lane >> 4;
@@ -460,11 +465,11 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__
     // is not part of the range check) and reads as ZERO instead of a copy of the last row.  Same results (those rows are never
     // stored), but the MFMAs of the padding multiply zeros: the chip is power-limited under this loop, and 96 of the 1280 padded
     // LLaMA rows doing no switching is worth 1.5-2.3 % on the M = 1184 launches (profiles/r04_gemm_x4.md).
-    const int zp = (flags & 0x20000000) ? 1 : 0;
+    const int zp = (flags & X4_F_ZERO_PAD) ? 1 : 0;
     const int swz = (4 * (wave & 1) + (lane >> 4)) & 7;
     const int ch = ((lane & 7) ^ swz) << 4;
 #if X4_NVARIANTS > 1
-    const int m0l = (flags & 0x40000000) ? 0 : m0, n0l = (flags & 0x40000000) ? 0 : n0;   // sweep builds: same-panel timing probe
+    const int m0l = (flags & X4_F_SAME_PANEL) ? 0 : m0, n0l = (flags & X4_F_SAME_PANEL) ? 0 : n0;   // sweep builds: same-panel timing probe
 #else
     const int m0l = m0, n0l = n0;
 #endif
@@ -531,7 +536,7 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__
 static int x4_variant = 0, x4_same_panel = 0, x4_zero_pad = -1;
 static void* x4_clock_probe = nullptr;
 static int x4_no_stores = 0;
-extern "C" void mhdbg_set_gemm_x4_no_stores(int on) { x4_no_stores = on; }   // TIMING PROBE
+extern "C" void mhdbg_set_gemm_x4_no_stores(int on) { x4_no_stores = on; }   // timing probe, tools/gemm_x8_clock.py
 extern "C" void mhdbg_set_gemm_x4_clock_probe(void* p) { x4_clock_probe = p; }   // debug: [8][4] int64 (shader cycles, 100-MHz ticks total / to the loop / to the loop's end) of workgroups 0, 64, ..
 extern "C" void mhdbg_set_gemm_x4_zero_pad(int on) { x4_zero_pad = on ? 1 : 0; }    // debug hook (tests, A/B): 0 = padding rows re-read the last row
 extern "C" void mhdbg_set_gemm_x4_same_panel(int on) { x4_same_panel = on; }                                   // sweep tool only
@@ -551,11 +556,11 @@ int mh_launch_gemm_x4(const void* A, int lda, const void* B, int ldb, void* C, i
   const int tiles_m = (M + X4_BM - 1) / X4_BM, tiles_n = (N + X4_BN - 1) / X4_BN;
   const size_t shmem = 2 * X4_BUF;   // 128 KiB -> one 4-wave workgroup per CU
   const dim3 grid(tiles_m * tiles_n, splits);
-  if (x4_same_panel) flags |= 0x40000000;
+  if (x4_same_panel) flags |= X4_F_SAME_PANEL;
   if (x4_zero_pad < 0) { const char* e = getenv("MYRIAD_GEMM_ZERO_PAD"); x4_zero_pad = (e && e[0] == '0') ? 0 : 1; }
-  if (x4_zero_pad) flags |= 0x20000000;
-  if (x4_no_stores) flags |= 0x08000000;
-  if (x4_clock_probe && !aux && !(flags & (MH_GEMM_SWIGLU_FWD | MH_GEMM_SWIGLU_BWD))) { flags |= 0x10000000; aux = x4_clock_probe; }
+  if (x4_zero_pad) flags |= X4_F_ZERO_PAD;
+  if (x4_no_stores) flags |= X4_F_NO_STORES;
+  if (x4_clock_probe && !aux && !(flags & (MH_GEMM_SWIGLU_FWD | MH_GEMM_SWIGLU_BWD))) { flags |= X4_F_CLOCK_PROBE; aux = x4_clock_probe; }
   if (g_mh_prof_on) mh_prof_pre(stream, 2, M, N, K, splits, flags);
 #define X4_LAUNCH(V)                                                                                                           \
   {                                                                                                                            \

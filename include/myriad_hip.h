@@ -8,8 +8,10 @@
  * dimensions in ELEMENTS, explicit hipStream_t, no hidden allocation (workspaces are passed in).  Library state is what
  * the caller registers: the split-K scratch -- in an opaque mh_ctx (mh_ctx_set_workspace + mh_ctx_make_current) or in the
  * process-default record (mh_set_workspace / mh_set_stream_workspace); one scratch per stream that may split K: two streams
- * must not share one -- plus a few switches read once from the environment (MYRIAD_SLAB_BF16, MYRIAD_SWIGLU_FUSED).
- * Calls on different streams with their own scratch are independent.
+ * must not share one -- the launch profiler's event pool (mh_prof_*, off unless started) and the option table below
+ * (mh_set_option / mh_get_option: on/off switches between equivalent code paths, each defaulting to the measured-best setting).
+ * The shipped library exports nothing else: the timing probes and sweep switches of tools/ (mhdbg_*) are compiled only into
+ * libmyriad_hip_dbg.so (-DMH_DEBUG_HOOKS).  Calls on different streams with their own scratch are independent.
  * Every function returns 0 on success or a negative MH_ERR_* code and never throws.
  * bf16 tensors are raw uint16 bit patterns; "f32" means IEEE float.
  */
@@ -41,14 +43,16 @@ int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, void* C, int
 
 /* Which kernel mh_gemm_bf16_nt will launch for this shape and with how many K splits (splits > 1 adds one
  * fixed-order reduce launch): *kernel = 0 weight-streaming gemv (M <= 16), 1 = 128x128x64 tile (gemm_nt_kernel),
- * 2 = 256x256x32 tile (gemm_256_kernel), 3 = gemm_nt_kernel with a 128x64 tile (grids that leave most CUs empty),
- * 4 / 5 = gemm_nt_kernel with a 160x128 / 160x96 tile and a 4-deep ring (128 < M <= 320: the batch-1 step's 148 / 257 rows
- * as one / two row tiles, the weight streamed once).
+ * 2 = 256x256x64 tile, eight waves, hand-scheduled K loop (gemm_x8_kernel; gemm_256_kernel, the 256x256x32 kernel of
+ * rounds 1-3, only for operands whose byte offsets pass 2 GiB or with option gemm256_impl = 0), 3 = gemm_nt_kernel with a
+ * 128x64 tile (grids that leave most CUs empty), 4 / 5 = gemm_nt_kernel with a 160x128 / 160x96 tile and a 4-deep ring
+ * (128 < M <= 320: the batch-1 step's 148 / 257 rows as one / two row tiles, the weight streamed once), 6 = gemm_nt_kernel
+ * with a 64x64 tile and an 8-deep ring (one-round grids with K <= 3072).
  * For profilers and benchmarks that attribute time per kernel. */
 int mh_gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits);
 
 /* Launch profiler (`roofline.achieved` is per launch of the dominant kernel): between mh_prof_start and
- * mh_prof_stop every launch of gemm_256_kernel / gemm_nt_kernel is bracketed by two HIP events on the stream it is launched
+ * mh_prof_stop every launch of gemm_x8_kernel / gemm_256_kernel / gemm_nt_kernel is bracketed by two HIP events on the stream it is launched
  * on -- the kernel alone, also when it is the partial-product launch of a split-K op.  Launches inside a stream capture are
  * skipped.  mh_prof_stop waits for the device and writes, per recorded launch i, meta[6i..6i+5] = (kernel id as
  * mh_gemm_plan numbers them, M, N, K, K splits, flags) and ms[i]; returns the number of records (<= cap).  The events
@@ -182,6 +186,15 @@ int mh_lora_dx(const float* dx_ext, long ld, const float* A, float* out, int M, 
  * the product goes through dx_ext_buf [M, D+64] (which then holds the border) and border_out is left alone. */
 int mh_gemm_lora_dx(const void* A, int lda, const void* Bw, int ldb, float* dx_ext_buf, const float* loraA, float* dxn,
                     float* border_out, int M, int D, int K, int R2, float s, float p, unsigned long long seed, mh_stream_t stream);
+/* mh_gemm_lora_dx followed by the backward of the RMSNorm whose output the qkv projection read (the layer's input norm,
+ * modeling_llama.py:66-74, 257-259 under autograd): dx = d rmsnorm(x; w)(dxn) + dres as f32 (dx) and / or bf16 (dx_bf16).
+ * With D <= 4096 and R2 = 16 the LoRA correction and the norm backward are ONE kernel that also sums the dgrad's split-K
+ * slabs (the [M, D] f32 dxn never exists); otherwise, or with option lora_norm_fused = 0, mh_lora_dx and mh_rmsnorm_bwd run
+ * back to back through dxn_buf [M, D] f32.  Same bits either way.  dx_ext_buf / border_out as in mh_gemm_lora_dx. */
+int mh_gemm_lora_rmsnorm_bwd(const void* A, int lda, const void* Bw, int ldb, float* dx_ext_buf, const float* loraA,
+                             float* dxn_buf, float* border_out, const float* x, const float* w, const float* dres, float* dx,
+                             void* dx_bf16, int M, int D, int K, int R2, float s, float p, unsigned long long seed, float eps,
+                             mh_stream_t stream);
 long mh_lora_wgrad_ws_floats(int D, int R2);
 int mh_lora_wgrad(const void* x, long ldx, const float* dx_ext, long ldg, const void* dq, const void* dv, long ldq,
                   const void* border, long ldb, float* dA, float* dBq, float* dBv, float* ws, int M, int D, int R2,
@@ -370,6 +383,26 @@ int mh_allreduce_wait(mh_ctx* ctx, mh_stream_t consumer);
 /* library identity */
 const char* mh_version(void);
 int mh_target_arch(void); /* 950 */
+
+/* Options: process-wide on/off switches between code paths that compute the same thing (the fused and the separate form of
+ * an op are bit-identical; tests flip them to prove it) or between stated precisions.  Each starts from its MYRIAD_<NAME>
+ * environment variable when set ("0" = off), else from the default:
+ *   slab_bf16 (1)       bf16 split-K slabs of the 256x256 kernel; 0 = fp32 slabs
+ *   gemm_skinny (1)     160-row tiles for 128 < M <= 320
+ *   swiglu_fused (1)    SiLU gate in the epilogues of the gate|up forward / down dgrad GEMMs
+ *   gelu_fused (1)      erf-GELU in the epilogues of the Q-Former MLP GEMMs
+ *   attn_bwd_split (1)  two workgroups per (batch, head) in mh_attn_rope_bwd when B*H <= 128
+ *   gemm_zero_pad (1)   rows past M / N of a 256x256 tile read as zeros; 0 = as copies of the last row
+ *   gemm256_impl (1)    plan kernel 2 = gemm_x8_kernel; 0 = gemm_256_kernel
+ *   lora_norm_fused (1) LoRA dx + input-norm backward as one kernel (mh_gemm_lora_rmsnorm_bwd), LoRA down inside the norm
+ *                       forward (mh_gemm_residual_rmsnorm_lora / mh_rmsnorm_lora_fwd)
+ * mh_set_option returns the previous value (0 / 1) or MH_ERR_ARG (unknown name, value not 0 / 1); mh_get_option the current
+ * value or MH_ERR_ARG.  Not thread-safe against concurrent launches. */
+int mh_set_option(const char* name, int value);
+int mh_get_option(const char* name);
+/* self-check of the hardware fp32 -> bf16 rounding (v_cvt_pk_bf16_f32) against the integer round-to-nearest-even form:
+   hw / hw_pk / sw [n] bf16 = scalar conversion, packed conversion, integer form of x[n] (n even) */
+int mh_bf16_round_check(const float* x, void* hw, void* hw_pk, void* sw, long n, mh_stream_t s);
 
 /* K17 image front-end (data path, SURVEY 8 f-2 image side): what datasets/datasets/anomaly_detection.py:118-122,246 and
  * processors/blip_processors.py:21-29,120-147,189-203 do on the CPU with torchvision + Pillow -- Resize(BICUBIC) ->

@@ -8,7 +8,8 @@ import re
 from typing import Dict, List, Tuple
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "libmyriad_hip.so")
+# MYRIAD_HIP_DEBUG_LIB=1 (set by the tools/ scripts that need a timing probe or a sweep switch) loads the -DMH_DEBUG_HOOKS build
+LIB_PATH = os.path.join(_PKG, "libmyriad_hip_dbg.so" if os.environ.get("MYRIAD_HIP_DEBUG_LIB") == "1" else "libmyriad_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_PKG), "include", "myriad_hip.h")
 
 _CT = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float, "double": ctypes.c_double,
@@ -64,6 +65,12 @@ def load() -> ctypes.CDLL:
     # loading this library before torch pulls in /opt/rocm's copy, and kernels registered with one runtime cannot be launched on
     # the other's streams (seen as MH_ERR_LAUNCH at the first launch when build() ran before smoke() in one process).
     import torch  # noqa: F401
+    import myriad_amd
+    if myriad_amd.KERNARG_SET_TOO_LATE:
+        import warnings
+        warnings.warn("myriad_amd was imported after the HIP runtime initialised: HIP_FORCE_DEV_KERNARG=1 did not take, kernel "
+                      "arguments stay in host memory (~2 % per step, more at batch 1).  Export it in the job's environment.",
+                      RuntimeWarning, stacklevel=2)
     lib = ctypes.CDLL(LIB_PATH)
     for name, (restype, argtypes) in signatures().items():
         try:

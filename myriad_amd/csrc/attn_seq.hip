@@ -654,10 +654,10 @@ extern "C" int mh_attn_rope_bwd(const void* qkv, int ld, const void* o, int ldo,
 
 extern "C" int mh_attn_rope_supported(int S, int D) { return (D == AS_D && S > 0 && S <= AS_MAXF * 16) ? 1 : 0; }
 
-static int g_as_split = -1;                            // MYRIAD_ATTN_BWD_SPLIT=0 keeps one workgroup per (batch, head) (A/B runs)
-extern "C" void mhdbg_set_attn_bwd_split(int on) { g_as_split = on ? 1 : 0; }   // debug hook (tests), not part of the ABI
 static long long* g_as_trace = nullptr;
-extern "C" void mhdbg_set_attn_seq_trace(void* ptr) { g_as_trace = (long long*)ptr; }   // debug hook, not part of the ABI
+#ifdef MH_DEBUG_HOOKS
+extern "C" void mhdbg_set_attn_seq_trace(void* ptr) { g_as_trace = (long long*)ptr; }   // phase stamps (libmyriad_hip_dbg.so only)
+#endif
 
 int mh_launch_attn_rope_bwd(const void* qkv, int ld, const void* o, int ldo, const void* dout, int dout_is_bf16, int nslab,
                             long slab, int ldd, const float* lse, void* dqkv, const int* pos, const float* cos_tab,
@@ -679,8 +679,8 @@ int mh_launch_attn_rope_bwd(const void* qkv, int ld, const void* o, int ldo, con
     (void)hipFuncSetAttribute((const void*)attn_seq_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)as_lds_bytes(true));
     attr = true;
   }
-  if (g_as_split < 0) { const char* e = getenv("MYRIAD_ATTN_BWD_SPLIT"); g_as_split = (e && e[0] == '0') ? 0 : 1; }
-  const int parts = (g_as_split && B * H <= 128) ? 2 : 1;
+  // option attn_bwd_split = 0 keeps one workgroup per (batch, head) (A/B runs)
+  const int parts = (mh_opt(MH_OPT_ATTN_BWD_SPLIT) && B * H <= 128) ? 2 : 1;
   hipLaunchKernelGGL(attn_seq_bwd_kernel, dim3(B * H, parts), dim3(AS_NW * 64), as_lds_bytes(true), stream, p);
   MH_CHECK_LAUNCH();
   return MH_OK;

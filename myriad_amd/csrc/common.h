@@ -31,6 +31,21 @@ struct MhScratch {
 extern MhScratch g_default_scratch;
 extern MhScratch* g_scratch;
 
+// Library options (version.hip: mh_set_option / mh_get_option; include/myriad_hip.h lists them).  Process-wide A/B switches, each
+// defaulting to the measured-best setting and to its MYRIAD_* environment variable when that is set; read through mh_opt().
+enum MhOpt {
+  MH_OPT_SLAB_BF16 = 0,     // bf16 split-K slabs of the 256x256 kernel (0: fp32)
+  MH_OPT_GEMM_SKINNY,       // 160-row tiles for 128 < M <= 320
+  MH_OPT_SWIGLU_FUSED,      // SiLU gate in the gate|up / down-dgrad GEMM epilogues
+  MH_OPT_GELU_FUSED,        // erf-GELU in the Q-Former MLP GEMM epilogues
+  MH_OPT_ATTN_BWD_SPLIT,    // two workgroups per (batch, head) in the LLaMA attention backward at small batch
+  MH_OPT_GEMM_ZERO_PAD,     // rows past M / N of the 256x256 tile read as zeros (0: copies of the last row)
+  MH_OPT_GEMM256_IMPL,      // 1: hand-scheduled 64-deep loop (gemm_x4.hip), 0: the eight-wave fallback kernel (gemm_256.hip)
+  MH_OPT_LORA_NORM_FUSED,   // LoRA dx correction + input-norm backward / LoRA down + norm forward as one kernel each
+  MH_OPT_COUNT
+};
+int mh_opt(int id);
+
 // launch profiler (prof.hip): no-ops unless mh_prof_start() was called
 extern bool g_mh_prof_on;
 void mh_prof_pre(hipStream_t s, int kernel, int M, int N, int K, int splits, int flags);
@@ -105,6 +120,24 @@ __device__ __forceinline__ float4_t slab_load4(const void* base, long idx, int s
     return (float4_t){bf2f((bf16_t)h[0]), bf2f((bf16_t)h[1]), bf2f((bf16_t)h[2]), bf2f((bf16_t)h[3])};
   }
   return *reinterpret_cast<const float4_t*>(reinterpret_cast<const float*>(base) + idx);
+}
+
+// Expression forms shared by kernels that must agree bit for bit (a fused kernel and the launches it replaces): explicit FMAs,
+// no implicit contraction, so the same bits come out whatever code surrounds the call.
+// LoRA dx (lora.hip): base + s * (acc_q * keep_q + acc_v * keep_v)
+__device__ __forceinline__ float lora_dx_value(float base, float s, float acc, float kq, float accv, float kv) {
+#pragma clang fp contract(off)
+  return __builtin_fmaf(s, __builtin_fmaf(acc, kq, accv * kv), base);
+}
+// RMSNorm backward (norm.hip): the two row sums and the output  r * w * g - x * cc
+__device__ __forceinline__ void rms_bwd_sums(float x, float w, float g, float& ss, float& dot) {
+#pragma clang fp contract(off)
+  ss = __builtin_fmaf(x, x, ss);
+  dot = __builtin_fmaf(x * w, g, dot);
+}
+__device__ __forceinline__ float rms_bwd_value(float r, float w, float g, float x, float cc) {
+#pragma clang fp contract(off)
+  return __builtin_fmaf(-x, cc, (r * w) * g);
 }
 
 __device__ __forceinline__ float wave_sum(float v) {

@@ -659,7 +659,7 @@ __global__ void bf16_round_check_kernel(const float* __restrict__ x, bf16_t* __r
   sw[2 * i] = f2bf_sw(a);
   sw[2 * i + 1] = f2bf_sw(b);
 }
-extern "C" int mhdbg_bf16_round_check(const float* x, void* hw, void* hw_pk, void* sw, long n, hipStream_t stream) {
+extern "C" int mh_bf16_round_check(const float* x, void* hw, void* hw_pk, void* sw, long n, hipStream_t stream) {
   if (n <= 0 || (n & 1)) return MH_ERR_ARG;
   hipLaunchKernelGGL(bf16_round_check_kernel, dim3((unsigned)((n / 2 + 255) / 256)), dim3(256), 0, stream, x, (bf16_t*)hw,
                      (bf16_t*)hw_pk, (bf16_t*)sw, n);

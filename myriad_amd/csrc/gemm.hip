@@ -454,11 +454,9 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const void* __r
 // LLaMA and ViT Linears, whose results are rounded to bf16 (or added to the fp32 residual stream) anyway; the partial sums cost
 // 2 x 4 B per output element per split in fp32 -- 9 GB per step at batch 8.  The 128x128 kernel's slabs (weight gradients: long
 // cancelling reductions over tokens) stay fp32.  *slab_bf16 tells the caller which it got.
-static int g_slab_bf16 = -1;
-extern "C" void mhdbg_set_slab_bf16(int on) { g_slab_bf16 = on ? 1 : 0; }   // debug hook (tests), not part of the ABI
 
 static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t stream, bool reduce = true, int* slab_bf16 = nullptr) {
-  if (g_slab_bf16 < 0) { const char* e = getenv("MYRIAD_SLAB_BF16"); g_slab_bf16 = (e && e[0] == '0') ? 0 : 1; }
+  const int g_slab_bf16 = mh_opt(MH_OPT_SLAB_BF16);
   const int nt = g0.K / 64;
   if (splits > nt) splits = nt;
   const int tps = (nt + splits - 1) / splits;
@@ -556,7 +554,9 @@ static int auto_splits(int M, int N, int K) {
 
 // 8-wave kernels run one workgroup per CU: pick the split count that best fills whole rounds of 256 workgroups
 static int g_force_big_splits = 0;
-extern "C" void mhdbg_set_big_splits(int s) { g_force_big_splits = s; }   // debug hook (sweep tools), not part of the ABI
+#ifdef MH_DEBUG_HOOKS
+extern "C" void mhdbg_set_big_splits(int s) { g_force_big_splits = s; }   // sweep tools (libmyriad_hip_dbg.so only)
+#endif
 
 static int big_tile_splits(int M, int N, int K, int tile_n) {
   if (g_force_big_splits > 0) return g_force_big_splits;
@@ -591,16 +591,17 @@ static inline int plan_variant(int kernel) {
 //             workgroup (Q-Former / VE-net shapes: 648x768 is 36 tiles).  A lone workgroup streams its operands at one
 //             CU's L2 rate (~0.5 us per 64-deep step), so twice the workgroups is twice the CUs pulling: 14 -> 10 us at
 //             K = 768, 27 -> 19 us at K = 2304 (tools/gemm_small_sweep.py); same k order per accumulator, same bits
-static int g_force_kernel = -1, g_force_splits = 0, g_skinny = -1;
-extern "C" void mhdbg_set_force_plan(int kernel, int splits) { g_force_kernel = kernel; g_force_splits = splits; }   // sweep tools
-extern "C" void mhdbg_set_skinny(int on) { g_skinny = on ? 1 : 0; }                                                 // A/B, tests
+static int g_force_kernel = -1, g_force_splits = 0;
+#ifdef MH_DEBUG_HOOKS
+extern "C" void mhdbg_set_force_plan(int kernel, int splits) { g_force_kernel = kernel; g_force_splits = splits; }   // sweep tools (libmyriad_hip_dbg.so only)
+#endif
 
 // One row tile of 160 for 128 < M <= 160 (the batch-1 step's 148 LLaMA rows), two for M <= 320 (its 257 ViT rows): the
 // weight matrix is streamed ONCE (the 128-row tile reads it twice and multiplies 108 padding rows, the 256-row tile
 // multiplies 108), 160 x 96 or 160 x 128 x 64 tiles with a 4-deep ring (3 K tiles in flight per CU), K split so that the
 // launch is one round of <= 256 workgroups.  Picks the column width / split count that fills the most CUs.
 static bool skinny_plan(int M, int N, int K, bool can_split, int* kernel, int* splits) {
-  if (g_skinny < 0) { const char* e = getenv("MYRIAD_GEMM_SKINNY"); g_skinny = (e && e[0] == '0') ? 0 : 1; }
+  const int g_skinny = mh_opt(MH_OPT_GEMM_SKINNY);
   // ... for weight matrices worth streaming (>= 4 M elements): the Q-Former / VE-net shapes stay on the 128x64 tiles
   if (!g_skinny || M <= 128 || M > 320 || N < 512 || K < 512 || (long)N * K < (4L << 20)) return false;
   const int tm = (M + 159) / 160;
@@ -819,6 +820,55 @@ extern "C" int mh_gemm_lora_dx(const void* A, int lda, const void* Bw, int ldb, 
   return mh_launch_lora_dx(dx_ext_buf, 0, N, 1, 0, loraA, dxn, nullptr, M, D, R2, s, p, seed, stream);
 }
 
+int mh_launch_lora_dx_rmsnorm_bwd(const void* dx_ext, int slab_bf16, long ld, int nslab, long slab, const float* A, const float* x,
+                                  const float* w, const float* dres, float* dx, void* dx_bf16, float* border_out, int M, int D,
+                                  int R2_, float s, float p, unsigned long long seed, float eps, hipStream_t stream);
+
+// mh_gemm_lora_dx followed by the backward of the RMSNorm whose output the qkv projection read (the layer's input norm):
+// dx = d rmsnorm(x; w)(dxn) + dres.  With D <= 4096 and r = 8 the LoRA correction and the norm backward are ONE kernel that sums
+// the dgrad's split-K slabs itself (lora.hip: lora_dx_rmsnorm_bwd_kernel); otherwise the two kernels run back to back through
+// dxn_buf [M, D] f32.  Same bits either way.  dx_ext_buf / border_out as in mh_gemm_lora_dx.
+extern "C" int mh_gemm_lora_rmsnorm_bwd(const void* A, int lda, const void* Bw, int ldb, float* dx_ext_buf, const float* loraA,
+                                        float* dxn_buf, float* border_out, const float* x, const float* w, const float* dres,
+                                        float* dx, void* dx_bf16, int M, int D, int K, int R2, float s, float p,
+                                        unsigned long long seed, float eps, hipStream_t stream) {
+  if (M <= 0) return MH_OK;
+  const int N = D + 64;
+  if (!loraA || !x || !w || D <= 0 || (D % 4) != 0) return MH_ERR_ARG;
+  int kernel = 1, splits = 1;
+  if (K > 0) gemm_plan(M, N, K, MH_GEMM_OUT_F32, &kernel, &splits);
+  const void* prod = dx_ext_buf;
+  int sbf = 0, sp = 1;
+  long slab = 0;
+  float* bout = nullptr;
+  if (splits > 1 && kernel != 0 && border_out && (K % 64) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 &&
+      !(((uintptr_t)A | (uintptr_t)Bw) & 15)) {
+    GemmArgs g = {A, lda, Bw, ldb, (void*)dx_ext_buf, N, M, N, K, nullptr, nullptr, 0, MH_GEMM_OUT_F32, 1.0f, 1, K / 64, 0L};
+    g.flags |= plan_variant(kernel) << MH_GEMM_VARIANT_SHIFT;
+    const int nt = K / 64;                          // the split count run_splitk will settle on
+    sp = splits > nt ? nt : splits;
+    const int tps = (nt + sp - 1) / sp;
+    sp = (nt + tps - 1) / tps;
+    float* wsp = ws_for(stream);
+    const int rc = run_splitk(g, splits, wsp, stream, /*reduce=*/false, &sbf);
+    if (rc) return rc;
+    prod = wsp; slab = (long)M * N; bout = border_out;
+  } else {
+    if (!dx_ext_buf) return MH_ERR_ARG;
+    const int rc = mh_gemm_bf16_nt(A, lda, Bw, ldb, dx_ext_buf, N, M, N, K, nullptr, nullptr, 0, MH_GEMM_OUT_F32, 1.0f, stream);
+    if (rc) return rc;
+  }
+  if (mh_opt(MH_OPT_LORA_NORM_FUSED)) {
+    const int rc = mh_launch_lora_dx_rmsnorm_bwd(prod, sbf, N, sp, slab, loraA, x, w, dres, dx, dx_bf16, bout, M, D, R2, s, p, seed,
+                                                 eps, stream);
+    if (rc != MH_ERR_UNSUPPORTED) return rc;
+  }
+  if (!dxn_buf) return MH_ERR_ARG;
+  const int rc = mh_launch_lora_dx(prod, sbf, N, sp, slab, loraA, dxn_buf, bout, M, D, R2, s, p, seed, stream);
+  if (rc) return rc;
+  return mh_launch_rmsnorm_bwd(dxn_buf, 0, 1, 0, D, x, w, dres, dx, dx_bf16, M, D, eps, stream);
+}
+
 int mh_launch_attn_rope_bwd(const void* qkv, int ld, const void* o, int ldo, const void* dout, int dout_is_bf16, int nslab,
                             long slab, int ldd, const float* lse, void* dqkv, const int* pos, const float* cos_tab,
                             const float* sin_tab, const int* kv_len, int B, int H, int S, int D, float scale,
@@ -868,8 +918,6 @@ extern "C" int mh_gemm_attn_rope_bwd(const void* A, int lda, const void* Bw, int
 extern "C" int mh_silu_mul_fwd_blk(const void* gu, void* h, int M, int I, int blk, hipStream_t stream);
 extern "C" int mh_silu_mul_bwd_blk(const void* dh, const void* gu, void* dgu, int M, int I, int blk, hipStream_t stream);
 
-static int g_swiglu_fused = -1;
-extern "C" void mhdbg_set_swiglu_fused(int on) { g_swiglu_fused = on ? 1 : 0; }   // debug hook (tests), not part of the ABI
 
 static bool swiglu_fusable(int M, int N, int K, int lda, int ldb, const void* A, const void* B) {
   int kernel = 1, splits = 1;
@@ -878,8 +926,7 @@ static bool swiglu_fusable(int M, int N, int K, int lda, int ldb, const void* A,
   // the read-out of a one-workgroup-per-CU GEMM was instruction-bound (integer bf16 rounding), so the elementwise work added
   // to it cost what the saved launch and round trip of dact / gu gave back.  With the hardware rounding the fused forms win:
   // 42.20 / 42.20 ms against 42.34 / 42.41 (late round 4).  On by default; MYRIAD_SWIGLU_FUSED=0 runs the separate launches.
-  if (g_swiglu_fused < 0) { const char* e = getenv("MYRIAD_SWIGLU_FUSED"); g_swiglu_fused = (e && e[0] == '0') ? 0 : 1; }
-  return g_swiglu_fused && kernel == 2 && splits == 1 && (N % 128) == 0 && (K % 64) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 &&
+  return mh_opt(MH_OPT_SWIGLU_FUSED) && kernel == 2 && splits == 1 && (N % 128) == 0 && (K % 64) == 0 && (lda % 8) == 0 && (ldb % 8) == 0 &&
          !(((uintptr_t)A | (uintptr_t)B) & 15);
 }
 
@@ -920,15 +967,12 @@ extern "C" int mh_gemm_swiglu_bwd(const void* dH, int lddh, const void* WdT, int
 // direction per BertLayer on a chain of ~400 dependent 5-15-us launches.
 extern "C" int mh_gelu_fwd(const void* x, void* y, long n, hipStream_t stream);
 extern "C" int mh_gelu_bwd(const void* dy, const void* x, void* dx, long n, hipStream_t stream);
-static int g_gelu_fused = -1;
-extern "C" void mhdbg_set_gelu_fused(int on) { g_gelu_fused = on ? 1 : 0; }   // debug hook (tests), not part of the ABI
 
 static bool gelu_fusable(int M, int N, int K, int* variant) {
-  if (g_gelu_fused < 0) { const char* e = getenv("MYRIAD_GELU_FUSED"); g_gelu_fused = (e && e[0] == '0') ? 0 : 1; }
   int kernel = 1, splits = 1;
   gemm_plan(M, N, K, 0, &kernel, &splits);
   *variant = plan_variant(kernel);
-  return g_gelu_fused && splits == 1 && (kernel == 1 || kernel == 3 || kernel == 6);
+  return mh_opt(MH_OPT_GELU_FUSED) && splits == 1 && (kernel == 1 || kernel == 3 || kernel == 6);
 }
 
 extern "C" int mh_gemm_gelu_fwd(const void* X, int ldx, const void* W, int ldw, const float* bias, void* pre, int ldpre, void* act,

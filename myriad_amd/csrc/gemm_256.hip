@@ -387,15 +387,15 @@ __global__ __launch_bounds__(512, 2) void gemm_256_kernel(const bf16_t* __restri
 }
 
 static long long* g2_trace = nullptr;
-extern "C" void mhdbg_set_gemm256_trace(void* p) { g2_trace = (long long*)p; }   // debug hook, not part of the ABI
+#ifdef MH_DEBUG_HOOKS
+extern "C" void mhdbg_set_gemm256_trace(void* p) { g2_trace = (long long*)p; }   // phase stamps (libmyriad_hip_dbg.so only)
+#endif
 
 // Round 4: the same tile as a four-wave, 64-deep, hand-scheduled instruction stream (gemm_x4.hip) for launches with long K
 // per workgroup; both kernels produce the same bits.  Debug hook: 0 eight-wave, 1 four-wave, 2 / -1 the policy below.
 int mh_launch_gemm_x4(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K, const float* bias,
                       const float* residual, int ldr, int flags, float alpha, int splits, int tps, long split_stride,
                       hipStream_t stream, void* aux, int ldaux);
-static int g2_impl = -1;
-extern "C" void mhdbg_set_gemm256_impl(int impl) { g2_impl = impl; }   // debug hook (A/B tools, tests), not part of the ABI
 
 // tps / split_stride as in gemm.hip (tps in 64-deep K tiles)
 int mh_launch_gemm_256(const void* A, int lda, const void* B, int ldb, void* C, int ldc, int M, int N, int K,
@@ -409,8 +409,7 @@ int mh_launch_gemm_256(const void* A, int lda, const void* B, int ldb, void* C, 
   // policy (tools/gemm_x4_sweep.py, profiles/r04_gemm_x4.md): the hand-scheduled 64-deep loop (gemm_x4.hip, eight-wave form)
   // is ahead of the kernel above on every shape of the step -- 1.31 against 1.49 us per 64-deep k-tile at the same ~13 us
   // outside the loop -- so it takes every launch of plan kernel 2 it supports.  MYRIAD_GEMM256_IMPL=0 keeps the kernel above.
-  if (g2_impl < 0) { const char* e = getenv("MYRIAD_GEMM256_IMPL"); g2_impl = (e && e[0] == '0') ? 0 : 1; }
-  if (g2_impl != 0 && !g2_trace) {
+  if (mh_opt(MH_OPT_GEMM256_IMPL) && !g2_trace) {
     const int rc = mh_launch_gemm_x4(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, flags, alpha, splits, tps, split_stride,
                                      stream, aux, ldaux);
     if (rc != MH_ERR_UNSUPPORTED) return rc;

@@ -30,7 +30,7 @@
 #define MH_GEMM_GELU 2
 // launcher-internal flag bits (never part of the ABI's flags): debug hooks of the sweep / probe tools and the padding policy
 #define X4_F_SAME_PANEL 0x40000000   // every workgroup stages tile (0, 0)'s panels (all-L2-hit timing probe; sweep builds)
-#define X4_F_ZERO_PAD 0x20000000     // rows past M / N read as zeros (default on; mhdbg_set_gemm_x4_zero_pad)
+#define X4_F_ZERO_PAD 0x20000000     // rows past M / N read as zeros (default on; option gemm_zero_pad)
 #define X4_F_CLOCK_PROBE 0x10000000  // aux = int64 stamps of workgroups 0, 64, .. (mhdbg_set_gemm_x4_clock_probe)
 #define X4_F_NO_STORES 0x08000000    // read-out without its global stores (mhdbg_set_gemm_x4_no_stores: timing only, wrong results)
 #define MH_GEMM_SWIGLU_FWD 16
@@ -533,15 +533,16 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__
   }
 }
 
-static int x4_variant = 0, x4_same_panel = 0, x4_zero_pad = -1;
+static int x4_variant = 0, x4_same_panel = 0;
 static void* x4_clock_probe = nullptr;
 static int x4_no_stores = 0;
-extern "C" void mhdbg_set_gemm_x4_no_stores(int on) { x4_no_stores = on; }   // timing probe, tools/gemm_x8_clock.py
-extern "C" void mhdbg_set_gemm_x4_clock_probe(void* p) { x4_clock_probe = p; }   // debug: [8][4] int64 (shader cycles, 100-MHz ticks total / to the loop / to the loop's end) of workgroups 0, 64, ..
-extern "C" void mhdbg_set_gemm_x4_zero_pad(int on) { x4_zero_pad = on ? 1 : 0; }    // debug hook (tests, A/B): 0 = padding rows re-read the last row
-extern "C" void mhdbg_set_gemm_x4_same_panel(int on) { x4_same_panel = on; }                                   // sweep tool only
-extern "C" void mhdbg_set_gemm_x4_variant(int v) { x4_variant = (v >= 0 && v < X4_NVARIANTS) ? v : 0; }   // sweep tool only
+#ifdef MH_DEBUG_HOOKS   // timing probes and sweep switches: libmyriad_hip_dbg.so only (tools/gemm_x8_clock.py, gemm_x4_sweep.py)
+extern "C" void mhdbg_set_gemm_x4_no_stores(int on) { x4_no_stores = on; }   // the read-out without its global stores: WRONG RESULTS
+extern "C" void mhdbg_set_gemm_x4_clock_probe(void* p) { x4_clock_probe = p; }   // [8][4] int64 (shader cycles, 100-MHz ticks total / to the loop / to the loop's end) of workgroups 0, 64, ..
+extern "C" void mhdbg_set_gemm_x4_same_panel(int on) { x4_same_panel = on; }
+extern "C" void mhdbg_set_gemm_x4_variant(int v) { x4_variant = (v >= 0 && v < X4_NVARIANTS) ? v : 0; }
 extern "C" int mhdbg_gemm_x4_nvariants() { return X4_NVARIANTS; }
+#endif
 
 // Same contract as mh_launch_gemm_256 (gemm_256.hip), which routes here; MH_ERR_UNSUPPORTED sends the caller back to the
 // eight-wave kernel (operands whose row offsets do not fit the 32-bit buffer offset).
@@ -557,8 +558,7 @@ int mh_launch_gemm_x4(const void* A, int lda, const void* B, int ldb, void* C, i
   const size_t shmem = 2 * X4_BUF;   // 128 KiB -> one 4-wave workgroup per CU
   const dim3 grid(tiles_m * tiles_n, splits);
   if (x4_same_panel) flags |= X4_F_SAME_PANEL;
-  if (x4_zero_pad < 0) { const char* e = getenv("MYRIAD_GEMM_ZERO_PAD"); x4_zero_pad = (e && e[0] == '0') ? 0 : 1; }
-  if (x4_zero_pad) flags |= X4_F_ZERO_PAD;
+  if (mh_opt(MH_OPT_GEMM_ZERO_PAD)) flags |= X4_F_ZERO_PAD;
   if (x4_no_stores) flags |= X4_F_NO_STORES;
   if (x4_clock_probe && !aux && !(flags & (MH_GEMM_SWIGLU_FWD | MH_GEMM_SWIGLU_BWD))) { flags |= X4_F_CLOCK_PROBE; aux = x4_clock_probe; }
   if (g_mh_prof_on) mh_prof_pre(stream, 2, M, N, K, splits, flags);

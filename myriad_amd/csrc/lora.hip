@@ -154,21 +154,150 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(const void* __restrict__ d
     }
     float4_t acc = (float4_t){0.f, 0.f, 0.f, 0.f}, accv = (float4_t){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < R2 / 2; ++j) {
-      acc[0] += g[j] * a[j][0]; acc[1] += g[j] * a[j][1]; acc[2] += g[j] * a[j][2]; acc[3] += g[j] * a[j][3];
-    }
+    for (int j = 0; j < R2 / 2; ++j)
 #pragma unroll
-    for (int j = R2 / 2; j < R2; ++j) {
-      accv[0] += g[j] * a[j][0]; accv[1] += g[j] * a[j][1]; accv[2] += g[j] * a[j][2]; accv[3] += g[j] * a[j][3];
-    }
+      for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(g[j], a[j][e], acc[e]);
+#pragma unroll
+    for (int j = R2 / 2; j < R2; ++j)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) accv[e] = __builtin_fmaf(g[j], a[j][e], accv[e]);
     float4_t o;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       float kq, kv;
       dropout_keep_pair(seed, (unsigned long long)((long)m * D + d + e), p, ik, kq, kv);
-      o[e] = base[e] + s * (acc[e] * kq + accv[e] * kv);
+      o[e] = lora_dx_value(base[e], s, acc[e], kq, accv[e], kv);
     }
     *reinterpret_cast<float4_t*>(out + (long)m * D + d) = o;
+  }
+}
+
+// lora_dx and the RMSNorm backward that consumes it (the layer's input norm, modeling_llama.py:66-74 under autograd) as ONE
+// kernel: the [M, D] fp32 d(xn) that lora_dx wrote and rmsnorm_bwd_kernel read back never exists, and one dependent launch
+// leaves the LLaMA backward chain per layer.  A workgroup owns LXN_ROWS token rows and walks D in chunks of 1024 columns (256
+// threads x 4): a thread loads ITS four columns of all R2 rows of A once per chunk and uses them for every row (A is read once
+// per workgroup from L2, not once per row), the rows' x and d(xn) values stay in registers between the row sums and the output
+// pass.  Same expressions (common.h: lora_dx_value / rms_bwd_sums / rms_bwd_value), same per-thread column sets, same
+// summation orders and the same 4-wave block reduction as lora_dx_kernel followed by rmsnorm_bwd_kernel: the results are
+// bit-identical to the two launches (tests/test_model_gpu.py).
+#define LXN_ROWS 4
+#define LXN_NCH 4            // D <= 4096
+template <int R2, int sbf>
+__global__ __launch_bounds__(256, 2) void lora_dx_rmsnorm_bwd_kernel(
+    const void* __restrict__ dx_ext, long ld, int nslab, long slab, const float* __restrict__ A, const float* __restrict__ x,
+    const float* __restrict__ w, const float* dres, float* dx, bf16_t* dx_bf, float* __restrict__ border_out, int M, int D,
+    float s, float p, unsigned long long seed, float eps) {
+  __shared__ float s_g[LXN_ROWS][R2];
+  __shared__ float s_red[2 * LXN_ROWS][4];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int m0 = blockIdx.x * LXN_ROWS;
+  const float ik = 1.f / (1.f - p);
+  // d(s*t): the R2 border values of each row, summed over the slabs in slab order
+  if (t < LXN_ROWS * R2) {
+    const int r = t / R2, j = t - r * R2, m = m0 + r;
+    float g = 0.f;
+    if (m < M) {
+      for (int k = 0; k < nslab; ++k) {
+        const long idx = (long)m * ld + (long)k * slab + D + j;
+        g += sbf ? bf2f(reinterpret_cast<const bf16_t*>(dx_ext)[idx]) : reinterpret_cast<const float*>(dx_ext)[idx];
+      }
+      if (border_out) border_out[(long)m * 64 + j] = g;
+    }
+    s_g[r][j] = g;
+  }
+  __syncthreads();
+  float4_t xv[LXN_ROWS][LXN_NCH], gv[LXN_ROWS][LXN_NCH];
+  float ss[LXN_ROWS], dot[LXN_ROWS];
+#pragma unroll
+  for (int r = 0; r < LXN_ROWS; ++r) ss[r] = dot[r] = 0.f;
+#pragma unroll
+  for (int c = 0; c < LXN_NCH; ++c) {
+    const int d = c * 1024 + t * 4;
+    if (d < D) {
+      float4_t a[R2];
+#pragma unroll
+      for (int j = 0; j < R2; ++j) a[j] = *reinterpret_cast<const float4_t*>(A + (long)j * D + d);
+      const float4_t ww = *reinterpret_cast<const float4_t*>(w + d);
+#pragma unroll
+      for (int r = 0; r < LXN_ROWS; ++r) {
+        const int m = (m0 + r) < M ? (m0 + r) : (M - 1);      // rows past M redo the last row; nothing of theirs is stored
+        const long r0 = (long)m * ld;
+        float4_t base = (float4_t){0.f, 0.f, 0.f, 0.f};
+        for (int k = 0; k < nslab; ++k) {
+          const float4_t bk = slab_load4(dx_ext, r0 + (long)k * slab + d, sbf);
+          base[0] += bk[0]; base[1] += bk[1]; base[2] += bk[2]; base[3] += bk[3];
+        }
+        const float4_t v = *reinterpret_cast<const float4_t*>(x + (long)m * D + d);
+        float4_t acc = (float4_t){0.f, 0.f, 0.f, 0.f}, accv = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < R2 / 2; ++j) {
+          const float g = s_g[r][j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(g, a[j][e], acc[e]);
+        }
+#pragma unroll
+        for (int j = R2 / 2; j < R2; ++j) {
+          const float g = s_g[r][j];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) accv[e] = __builtin_fmaf(g, a[j][e], accv[e]);
+        }
+        float4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float kq, kv;
+          dropout_keep_pair(seed, (unsigned long long)((long)m * D + d + e), p, ik, kq, kv);
+          o[e] = lora_dx_value(base[e], s, acc[e], kq, accv[e], kv);
+          rms_bwd_sums(v[e], ww[e], o[e], ss[r], dot[r]);
+        }
+        xv[r][c] = v;
+        gv[r][c] = o;
+      }
+    }
+  }
+  // the block reductions of rmsnorm_bwd_kernel (wave butterfly, then the four wave sums added in wave order), all rows at once
+#pragma unroll
+  for (int r = 0; r < LXN_ROWS; ++r) {
+    const float a = wave_sum(ss[r]), b = wave_sum(dot[r]);
+    if (lane == 0) { s_red[2 * r][wave] = a; s_red[2 * r + 1][wave] = b; }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < LXN_ROWS; ++r) {
+    float a = 0.f, b = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { a += s_red[2 * r][i]; b += s_red[2 * r + 1][i]; }
+    ss[r] = a;
+    dot[r] = b;
+  }
+#pragma unroll
+  for (int c = 0; c < LXN_NCH; ++c) {
+    const int d = c * 1024 + t * 4;
+    if (d < D) {
+      const float4_t ww = *reinterpret_cast<const float4_t*>(w + d);
+#pragma unroll
+      for (int r = 0; r < LXN_ROWS; ++r) {
+        const long m = m0 + r;
+        if (m < M) {
+          const float rr = rsqrtf(ss[r] / D + eps);
+          const float cc = rr * rr * rr * dot[r] / D;
+          float4_t o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) o[e] = rms_bwd_value(rr, ww[e], gv[r][c][e], xv[r][c][e], cc);
+          if (dres) {
+            const float4_t dd = *reinterpret_cast<const float4_t*>(dres + m * D + d);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += dd[e];
+          }
+          if (dx) *reinterpret_cast<float4_t*>(dx + m * D + d) = o;
+          if (dx_bf) {
+            uint2 pk;
+            pk.x = pack_bf2(o[0], o[1]);
+            pk.y = pack_bf2(o[2], o[3]);
+            *reinterpret_cast<uint2*>(dx_bf + m * D + d) = pk;
+          }
+        }
+      }
+    }
   }
 }
 
@@ -365,6 +494,25 @@ int mh_launch_lora_dx(const void* dx_ext, int slab_bf16, long ld, int nslab, lon
     LORA_DISPATCH(R2_, hipLaunchKernelGGL((lora_dx_kernel<R2, 0>), grid, dim3(256), 0, stream, dx_ext, ld, A, out, M, D, s, p, seed,
                                           rows_per, nslab, slab, border_out));
   }
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// lora_dx + rmsnorm_bwd in one launch (D <= 4096); MH_ERR_UNSUPPORTED sends the caller to the two-launch form
+int mh_launch_lora_dx_rmsnorm_bwd(const void* dx_ext, int slab_bf16, long ld, int nslab, long slab, const float* A, const float* x,
+                                  const float* w, const float* dres, float* dx, void* dx_bf16, float* border_out, int M, int D,
+                                  int R2_, float s, float p, unsigned long long seed, float eps, hipStream_t stream) {
+  if (M <= 0) return MH_OK;
+  if (D % 4 || ld % 4 || ld < D + R2_ || p < 0.f || p >= 1.f || nslab < 1 || R2_ > 64) return MH_ERR_ARG;
+  if (D > 1024 * LXN_NCH) return MH_ERR_UNSUPPORTED;
+  const dim3 grid((M + LXN_ROWS - 1) / LXN_ROWS);
+  if (R2_ != 16) return MH_ERR_UNSUPPORTED;          // r = 8 (the shipped config); r = 16 would spill its 128 registers of A
+  if (slab_bf16)
+    hipLaunchKernelGGL((lora_dx_rmsnorm_bwd_kernel<16, 1>), grid, dim3(256), 0, stream, dx_ext, ld, nslab, slab, A, x, w, dres, dx,
+                       (bf16_t*)dx_bf16, border_out, M, D, s, p, seed, eps);
+  else
+    hipLaunchKernelGGL((lora_dx_rmsnorm_bwd_kernel<16, 0>), grid, dim3(256), 0, stream, dx_ext, ld, nslab, slab, A, x, w, dres, dx,
+                       (bf16_t*)dx_bf16, border_out, M, D, s, p, seed, eps);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

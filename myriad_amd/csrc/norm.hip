@@ -57,10 +57,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_bwd_kernel(const void* __restrict_
     if (nslab > 1) { g[0] *= 1.0f; g[1] *= 1.0f; g[2] *= 1.0f; g[3] *= 1.0f; }   // splitk_reduce_kernel's alpha
     const float4_t ww = *reinterpret_cast<const float4_t*>(w + i);
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      ss += v[e] * v[e];
-      dot += v[e] * ww[e] * g[e];
-    }
+    for (int e = 0; e < 4; ++e) rms_bwd_sums(v[e], ww[e], g[e], ss, dot);
     xv[c] = v;
     gv[c] = g;
   }
@@ -73,7 +70,7 @@ __global__ __launch_bounds__(NT) void rmsnorm_bwd_kernel(const void* __restrict_
     const float4_t ww = *reinterpret_cast<const float4_t*>(w + i);
     float4_t o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) o[e] = r * ww[e] * gv[c][e] - xv[c][e] * cc;
+    for (int e = 0; e < 4; ++e) o[e] = rms_bwd_value(r, ww[e], gv[c][e], xv[c][e], cc);
     if (dres) {
       const float4_t d = *reinterpret_cast<const float4_t*>(dres + row * D + i);
 #pragma unroll

@@ -228,11 +228,12 @@ class LlamaHIP:
                 ops.rope_(dqkv, 0, 2 * H, hd, sv["pos"], self.cos, self.sin, -1.0)
             if self.lora is None:
                 dxn = ops.gemm(dqkv, L["wqkvT"], out_dtype=F32)
+                dh, dh_b = ops.rmsnorm_bwd(dxn, h_in, L["ln1"], self.eps, dres=dh2, want_bf16=True)
             else:
-                # [M, D+64] = base dgrad | d(s*t), and the LoRA correction of dxn, in one call (split-K slabs summed in the dx kernel)
-                dxn = self.lora.backward_from_dqkv(li, dqkv, L["wqkvT_ext"], lsave[0], lsave[1], lsave[2],
-                                                   defer_wgrad=self.defer_lora_wgrad)
-            dh, dh_b = ops.rmsnorm_bwd(dxn, h_in, L["ln1"], self.eps, dres=dh2, want_bf16=True)
+                # [M, D+64] = base dgrad | d(s*t), the LoRA correction of d(xn) and the input norm's backward in one call: the
+                # split-K slabs are summed inside the one kernel that does both (csrc/lora.hip)
+                dh, dh_b = self.lora.backward_from_dqkv_norm(li, dqkv, L["wqkvT_ext"], lsave[0], lsave[1], lsave[2], h_in,
+                                                             L["ln1"], self.eps, dh2, defer_wgrad=self.defer_lora_wgrad)
         self._saved = None
         if self.lora is not None:
             self.lora.run_deferred_wgrads()

@@ -170,6 +170,37 @@ class LoraQV:
         self._queue_wgrad(layer_idx, (keep, gptr, ldg), dqkv, x_ext, p, seed, defer_wgrad)
         return dxn
 
+    def backward_from_dqkv_norm(self, layer_idx: int, dqkv: torch.Tensor, wqkvT_ext: torch.Tensor, x_ext: torch.Tensor, p: float,
+                                seed: int, h_in: torch.Tensor, norm_w: torch.Tensor, eps: float, dres: torch.Tensor,
+                                defer_wgrad: bool = False, want_bf16: bool = True):
+        """backward_from_dqkv() and the backward of the layer's input RMSNorm (modeling_llama.py:257-259 under autograd) in one
+        library call (mh_gemm_lora_rmsnorm_bwd): at D <= 4096, r = 8 the LoRA dx correction and the norm backward are one kernel
+        that sums the dgrad's split-K slabs itself, so d(xn) [M, D] is never written.  Returns (dh f32, dh bf16) -- the gradient
+        of the residual stream below this layer."""
+        D, r = self.D, self.r
+        M, K = dqkv.shape
+        _, splits = ops.gemm_plan(M, D + BORDER, K)
+        A = self._aqv(self.P, layer_idx)
+        lib = _lib.load()
+        fused = bool(lib.mh_get_option(b"lora_norm_fused")) and D <= 4096 and 2 * r == 16
+        dxn = None if fused else torch.empty((M, D), dtype=F32, device=self.dev)
+        if splits > 1:
+            border = torch.empty((M, BORDER), dtype=F32, device=self.dev)
+            keep, gptr, ldg, buf_ptr = border, border.data_ptr() - 4 * D, BORDER, None
+        else:
+            buf = torch.empty((M, D + BORDER), dtype=F32, device=self.dev)
+            keep, gptr, ldg, buf_ptr, border = buf, buf.data_ptr(), buf.stride(0), buf.data_ptr(), None
+        dh = torch.empty((M, D), dtype=F32, device=self.dev)
+        dhb = torch.empty((M, D), dtype=BF16, device=self.dev) if want_bf16 else None
+        _lib.check(lib.mh_gemm_lora_rmsnorm_bwd(dqkv.data_ptr(), dqkv.stride(0), wqkvT_ext.data_ptr(), wqkvT_ext.stride(0), buf_ptr,
+                                                A.data_ptr(), None if dxn is None else dxn.data_ptr(),
+                                                None if border is None else border.data_ptr(), h_in.data_ptr(), norm_w.data_ptr(),
+                                                dres.data_ptr(), dh.data_ptr(), None if dhb is None else dhb.data_ptr(), M, D, K,
+                                                2 * r, self.s, p, seed, float(eps), ops._s()),
+                   f"mh_gemm_lora_rmsnorm_bwd M={M} K={K}")
+        self._queue_wgrad(layer_idx, (keep, gptr, ldg), dqkv, x_ext, p, seed, defer_wgrad)
+        return dh, dhb
+
     def _queue_wgrad(self, layer_idx, g, dqkv, x_ext, p, seed, defer_wgrad) -> None:
         if defer_wgrad:
             self._deferred.append((layer_idx, g, dqkv, x_ext, p, seed))

@@ -162,7 +162,7 @@ def gemm(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None, b
     return out
 
 
-GEMM_KERNEL_NAMES = {0: "gemv_kernel", 1: "gemm_nt_kernel", 2: "gemm_256_kernel", 3: "gemm_nt_kernel", 4: "gemm_nt_kernel",
+GEMM_KERNEL_NAMES = {0: "gemv_kernel", 1: "gemm_nt_kernel", 2: "gemm_x8_kernel", 3: "gemm_nt_kernel", 4: "gemm_nt_kernel",
                      5: "gemm_nt_kernel", 6: "gemm_nt_kernel"}   # 3: 128x64 tile; 4 / 5: 160x128 / 160x96 row tile (M <= 320); 6: 64x64, 8-deep ring
 
 

@@ -28,6 +28,27 @@ def test_header_parses_and_library_exports_every_symbol():
     out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
     exported = {ln.split()[-1] for ln in out.splitlines() if " T mh_" in ln}
     assert exported == set(sigs), exported ^ set(sigs)
+    # ... and no debug hook at all: the timing probes / sweep switches of tools/ (one of them, the read-out without its stores,
+    # produces wrong results on purpose) exist only in libmyriad_hip_dbg.so, built from the same sources with -DMH_DEBUG_HOOKS
+    assert not [ln for ln in out.splitlines() if "mhdbg_" in ln]
+    dbg = os.path.join(os.path.dirname(_lib.LIB_PATH), "libmyriad_hip_dbg.so")
+    out_dbg = subprocess.check_output(["nm", "-D", "--defined-only", dbg], text=True)
+    hooks = {ln.split()[-1] for ln in out_dbg.splitlines() if " T mhdbg_" in ln}
+    assert {"mhdbg_set_gemm_x4_no_stores", "mhdbg_set_gemm_x4_same_panel", "mhdbg_set_gemm_x4_clock_probe",
+            "mhdbg_set_gemm_x4_variant", "mhdbg_set_force_plan"} <= hooks
+    assert {ln.split()[-1] for ln in out_dbg.splitlines() if " T mh_" in ln} == set(sigs)
+
+
+def test_options_are_named_switches_with_defaults():
+    lib = _lib.load()
+    for name in (b"slab_bf16", b"gemm_skinny", b"swiglu_fused", b"gelu_fused", b"attn_bwd_split", b"gemm_zero_pad",
+                 b"gemm256_impl", b"lora_norm_fused"):
+        assert lib.mh_get_option(name) in (0, 1)
+    assert lib.mh_get_option(b"no_such_option") == -1 and lib.mh_set_option(b"no_such_option", 1) == -1
+    assert lib.mh_set_option(b"gelu_fused", 2) == -1
+    prev = lib.mh_set_option(b"gelu_fused", 0)
+    assert lib.mh_get_option(b"gelu_fused") == 0
+    assert lib.mh_set_option(b"gelu_fused", prev) == 0 and lib.mh_get_option(b"gelu_fused") == prev
 
 
 def test_gemm_signature_is_plain_c():

@@ -107,12 +107,12 @@ def test_bf16_split_k_slabs_stay_inside_the_stated_tolerances(model):
     lib = _lib.load()
     s = samples(8, seed=23)
     try:
-        lib.mhdbg_set_slab_bf16(0)
+        lib.mh_set_option(b"slab_bf16", 0)
         l32, g32 = loss_and_grad(model, s)
-        lib.mhdbg_set_slab_bf16(1)
+        lib.mh_set_option(b"slab_bf16", 1)
         l16, g16 = loss_and_grad(model, s)
     finally:
-        lib.mhdbg_set_slab_bf16(1)
+        lib.mh_set_option(b"slab_bf16", 1)
     assert l32 != l16                                             # the switch does reach the kernels
     assert abs(l16 - l32) < 1e-3 * abs(l32), (l16, l32)
     assert float((g16 - g32).abs().max()) < 5e-2 * float(g32.abs().max())

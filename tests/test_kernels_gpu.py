@@ -15,6 +15,13 @@ from oracle import myriad_ref as R  # noqa: E402
 DEV = "cuda"
 
 
+def _opt_hook(name: str):
+    """Setter of a library option (include/myriad_hip.h: mh_set_option): the A/B switch between two forms of one op."""
+    from myriad_amd import _lib as L
+    lib = L.load()
+    return lambda v: lib.mh_set_option(name.encode(), int(v))
+
+
 def bf(x):
     return x.to(torch.bfloat16)
 
@@ -93,7 +100,7 @@ def slab_tol(M, N, K, tight):
 def _slab_hook():
     import ctypes
     from myriad_amd import _lib as L
-    return ctypes.CDLL(L.LIB_PATH).mhdbg_set_slab_bf16
+    return _opt_hook("slab_bf16")
 
 
 @pytest.mark.parametrize("slab_bf16", [1, 0])
@@ -152,7 +159,7 @@ def test_four_wave_and_eight_wave_instances_of_the_256_tile_are_bit_identical(M,
     k-tile counts (1, 2, 3, 5, ... k-tiles: the loop's one-tile, two-tile and steady paths), ragged M and N edges, K splits."""
     import ctypes
     from myriad_amd import _lib as L
-    hook = ctypes.CDLL(L.LIB_PATH).mhdbg_set_gemm256_impl
+    hook = _opt_hook("gemm256_impl")
     ops.ensure_workspace(torch.device(DEV))
     a = bf(rnd(M, K, seed=31)).to(DEV)
     b = bf(rnd(N, K, seed=32) * 0.05 + torch.arange(N)[:, None] * 1e-4).to(DEV)
@@ -184,10 +191,7 @@ def test_bf16_rounding_in_hardware_equals_the_integer_form():
     for a NaN."""
     import ctypes
     from myriad_amd import _lib as L
-    lib = ctypes.CDLL(L.LIB_PATH)
-    fn = lib.mhdbg_bf16_round_check
-    fn.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_long, ctypes.c_void_p]
-    fn.restype = ctypes.c_int
+    fn = L.load().mh_bf16_round_check
     hi = torch.arange(65536, dtype=torch.int64)
     lows = torch.tensor([0x0000, 0x0001, 0x7fff, 0x8000, 0x8001, 0xffff, 0x1234, 0xfedc], dtype=torch.int64)
     bits = ((hi[:, None] << 16) | lows[None, :]).reshape(-1)
@@ -211,10 +215,10 @@ def test_bf16_rounding_in_hardware_equals_the_integer_form():
 def test_padding_rows_of_the_256_tile_read_zeros_and_change_nothing(M, N, K, pad):
     """The 256 x 256 kernel reads the rows past M / N as zeros (one row past the end lies outside the buffer descriptor's range)
     instead of copies of the last row -- the padding MFMAs then switch nothing on a power-limited chip.  Same bits as with the
-    copies (mhdbg_set_gemm_x4_zero_pad(0)), for row strides wider than K and for operands that end exactly at their allocation."""
+    copies (option gemm_zero_pad = 0), for row strides wider than K and for operands that end exactly at their allocation."""
     import ctypes
     from myriad_amd import _lib as L
-    hook = ctypes.CDLL(L.LIB_PATH).mhdbg_set_gemm_x4_zero_pad
+    hook = _opt_hook("gemm_zero_pad")
     ops.ensure_workspace(torch.device(DEV))
     a = bf(rnd(M, K + pad, seed=231)).to(DEV)[:, :K]                 # lda = K + pad; the last row ends `pad` elements before the allocation does
     b = bf(rnd(N, K + pad, seed=232) * 0.05).to(DEV)[:, :K]
@@ -494,11 +498,11 @@ def test_attention_online_softmax_spike():
 def test_swiglu_fused_into_the_mlp_gemms(M, I, K):
     """mh_gemm_swiglu_fwd/bwd (SiLU-gated product in the gate|up GEMM's epilogue, its backward in the down dgrad's) against
     an fp32 torch model of LlamaMLP (modeling_llama.py:139-140) and bit-for-bit against GEMM + silu kernels.  The fused
-    epilogues are the default since the read-out rounds in hardware (MYRIAD_SWIGLU_FUSED=0: the separate launches); the debug
-    hook selects them explicitly."""
+    epilogues are the default since the read-out rounds in hardware (MYRIAD_SWIGLU_FUSED=0: the separate launches); the option
+    selects them explicitly."""
     import ctypes
     from myriad_amd import _lib as L
-    hook = ctypes.CDLL(L.LIB_PATH).mhdbg_set_swiglu_fused
+    hook = _opt_hook("swiglu_fused")
     ops.ensure_workspace(torch.device(DEV))
     hook(1)
     try:
@@ -547,7 +551,7 @@ def test_gelu_fused_into_the_mlp_gemms(M, N, K, D):
     does not (the ViT's 256-tile product, a 16-row GEMV), where the entry points run the two launches themselves."""
     import ctypes
     from myriad_amd import _lib as L
-    hook = ctypes.CDLL(L.LIB_PATH).mhdbg_set_gelu_fused
+    hook = _opt_hook("gelu_fused")
     ops.ensure_workspace(torch.device(DEV))
     x = bf(rnd(M, K, seed=171, scale=0.5)).to(DEV)
     w1 = bf(rnd(N, K, seed=172, scale=0.08)).to(DEV)
@@ -645,8 +649,6 @@ def test_attention_rope_bwd_two_workgroups_per_head_same_bits():
     import ctypes
     from myriad_amd import _lib
     lib = _lib.load()
-    lib.mhdbg_set_attn_bwd_split.argtypes = [ctypes.c_int]
-    lib.mhdbg_set_attn_bwd_split.restype = None
     B, H, S, D = 2, 4, 148, 128
     W = H * D
     qkv = bf(rnd(B, S, 3 * W, seed=61)).to(DEV)
@@ -656,12 +658,12 @@ def test_attention_rope_bwd_two_workgroups_per_head_same_bits():
     o, lse = ops.attn_rope_fwd(qkv, H, D, scale, pos, cos, sin)
     dout = bf(rnd(B, S, W, seed=62)).to(DEV)
     try:
-        lib.mhdbg_set_attn_bwd_split(0)
+        lib.mh_set_option(b"attn_bwd_split", 0)
         one = ops.attn_rope_bwd(qkv, o, dout, lse, H, D, scale, pos, cos, sin).clone()
-        lib.mhdbg_set_attn_bwd_split(1)
+        lib.mh_set_option(b"attn_bwd_split", 1)
         two = ops.attn_rope_bwd(qkv, o, dout, lse, H, D, scale, pos, cos, sin).clone()
     finally:
-        lib.mhdbg_set_attn_bwd_split(1)
+        lib.mh_set_option(b"attn_bwd_split", 1)
     assert torch.equal(one, two)
 
 

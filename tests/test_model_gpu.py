@@ -17,7 +17,7 @@ from myriad_amd.llama import LlamaHIP  # noqa: E402
 from myriad_amd.myriad import MiniGPT4HIP, MyriadHIP  # noqa: E402
 from myriad_amd.networks import from_reference_layout  # noqa: E402
 from myriad_amd.qformer import QFormerHIP  # noqa: E402
-from myriad_amd import ops  # noqa: E402
+from myriad_amd import _lib as L, ops  # noqa: E402
 from oracle import myriad_ref as R  # noqa: E402
 from tests import golden_utils as gu  # noqa: E402
 
@@ -561,6 +561,51 @@ def test_lora_backward_fused_with_the_qkv_dgrad_is_bit_identical():
         outs.append((dxn.clone(), st.flat_g.clone()))
     assert torch.equal(outs[0][0], outs[1][0])
     assert torch.equal(outs[0][1], outs[1][1]) and float(outs[0][1].abs().sum()) > 0
+
+
+@pytest.mark.parametrize("M,K,p", [(1184, 12288, 0.05), (1184, 12288, 0.0), (148, 12288, 0.05), (37, 12288, 0.05)])
+def test_lora_dx_and_the_input_norm_backward_in_one_kernel_are_bit_identical(M, K, p):
+    """mh_gemm_lora_rmsnorm_bwd (LoRA dx correction + the input RMSNorm's backward as ONE kernel that also sums the dgrad's
+    split-K slabs: csrc/lora.hip lora_dx_rmsnorm_bwd_kernel) against the same call with option lora_norm_fused = 0 (lora_dx ->
+    [M, D] f32 -> rmsnorm_bwd) and against the three separate calls: same dh (f32 and bf16), same dA / dB, bit for bit --
+    at the training shape (split K, bf16 slabs), at batch 1 and at 37 rows (fp32 slabs, up to 15 of them; a ragged last row
+    group, M % 4 != 0), with and without dropout."""
+    from myriad_amd.lora import BORDER, LoraQV, lora_param_specs
+    from myriad_amd.myriad import ParamStore
+    ops.ensure_workspace(torch.device(DEV))
+    D, r = 4096, 8
+    lib = L.load()
+    gen = torch.Generator().manual_seed(177)
+    outs = []
+    for mode in ("fused", "unfused_option", "three_calls"):
+        st = ParamStore(lora_param_specs(1, D, r), DEV)
+        g2 = torch.Generator().manual_seed(178)
+        for name, ishape, _ in st.specs:
+            st.p[name].copy_(torch.randn(ishape, generator=g2) * 0.05)
+        lora = LoraQV(1, D, r, 16.0, p, st.p, st.g, DEV)
+        gen.manual_seed(179)
+        dqkv = (torch.randn(M, K, generator=gen) * 0.02).to(DEV).to(torch.bfloat16)
+        wT = (torch.randn(D + BORDER, K, generator=gen) * 0.02).to(DEV).to(torch.bfloat16)
+        x_ext = (torch.randn(M, D + BORDER, generator=gen) * 0.5).to(DEV).to(torch.bfloat16)
+        h_in = torch.randn(M, D, generator=gen).to(DEV)
+        w = (1.0 + 0.1 * torch.randn(D, generator=gen)).to(DEV)
+        dres = torch.randn(M, D, generator=gen).to(DEV)
+        seed = 123456789
+        prev = lib.mh_set_option(b"lora_norm_fused", 0 if mode == "unfused_option" else 1)
+        try:
+            if mode == "three_calls":
+                dxn = lora.backward_from_dqkv(0, dqkv, wT, x_ext, p, seed)
+                dh, dhb = ops.rmsnorm_bwd(dxn, h_in, w, 1e-6, dres=dres, want_bf16=True)
+            else:
+                dh, dhb = lora.backward_from_dqkv_norm(0, dqkv, wT, x_ext, p, seed, h_in, w, 1e-6, dres)
+        finally:
+            lib.mh_set_option(b"lora_norm_fused", prev)
+        torch.cuda.synchronize()
+        outs.append((dh.clone(), dhb.clone(), st.flat_g.clone()))
+    for o in outs[1:]:
+        assert torch.equal(outs[0][0], o[0]) and torch.equal(outs[0][1], o[1])
+        assert torch.equal(outs[0][2], o[2])
+    assert float(outs[0][2].abs().sum()) > 0 and bool(torch.isfinite(outs[0][0]).all())
 
 
 @pytest.mark.parametrize("dropout", [0.0, 0.05])

@@ -4,6 +4,7 @@ fed by the o_proj dgrad's split-K slabs as in the step: python tools/attn_seq_ph
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import os as _os; _os.environ.setdefault("MYRIAD_HIP_DEBUG_LIB", "1")   # the mhdbg_* hooks live in libmyriad_hip_dbg.so
 from myriad_amd import ops, _lib
 L = _lib.load()
 L.mhdbg_set_attn_seq_trace.argtypes = [ctypes.c_void_p]

@@ -5,6 +5,7 @@ timed by HIP events.  Usage: python tools/gemm_m148_sweep.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import os as _os; _os.environ.setdefault("MYRIAD_HIP_DEBUG_LIB", "1")   # the mhdbg_* hooks live in libmyriad_hip_dbg.so
 from myriad_amd import ops, _lib
 L = _lib.load()
 dev = torch.device("cuda:0")
@@ -30,11 +31,11 @@ for (M, N, K) in SHAPES:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16)
     bs = [torch.randn(N, K, device=dev).to(torch.bfloat16) * 0.05 for _ in range(nb)]
     out = torch.empty(M, N, dtype=torch.bfloat16, device=dev)
-    L.mhdbg_set_skinny(0)
+    L.mh_set_option(b"gemm_skinny", 0)
     k0, s0 = ops.gemm_plan(M, N, K)
     ref = ops.gemm(a, bs[0]).clone()
     t_old = timeit(lambda b: ops.gemm(a, b, out=out), bs)
-    L.mhdbg_set_skinny(1)
+    L.mh_set_option(b"gemm_skinny", 1)
     k1, s1 = ops.gemm_plan(M, N, K)
     got = ops.gemm(a, bs[0]).clone()
     err = float((got.float() - ref.float()).abs().max() / ref.float().abs().max())

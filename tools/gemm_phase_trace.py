@@ -4,9 +4,10 @@ boundaries of every k-tile interval): cycles per phase, averaged over intervals 
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import os as _os; _os.environ.setdefault("MYRIAD_HIP_DEBUG_LIB", "1")   # the mhdbg_* hooks live in libmyriad_hip_dbg.so
 from myriad_amd import ops, _lib
 dev = torch.device("cuda:0")
-cdll = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(_lib.__file__)), "libmyriad_hip.so"))
+cdll = ctypes.CDLL(_lib.LIB_PATH)
 cdll.mhdbg_set_gemm256_trace.argtypes = [ctypes.c_void_p]
 M, N, K = [int(x) for x in (sys.argv[1:4] if len(sys.argv) > 3 else (1184, 12288, 4096))]
 a = torch.randn(M, K, device=dev).to(torch.bfloat16)

@@ -4,6 +4,7 @@
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import os as _os; _os.environ.setdefault("MYRIAD_HIP_DEBUG_LIB", "1")   # the mhdbg_* hooks live in libmyriad_hip_dbg.so
 from myriad_amd import ops, _lib
 L = _lib.load()
 dev = torch.device("cuda:0")
@@ -30,7 +31,7 @@ for (M, N, K, f32, hb, hr) in SHAPES:
     outs = []
     times = {}
     for impl in (0, 1):
-        L.mhdbg_set_gemm256_impl(impl)
+        L.mh_set_option(b"gemm256_impl", impl)
         out = torch.full((M, N), 7.0, dtype=dt, device=dev)
         ops.gemm(a, bs[0], out=out, bias=bias, residual=res, variant=12)
         torch.cuda.synchronize()
@@ -57,6 +58,6 @@ for (M, N, K, f32, hb, hr) in SHAPES:
                           f"  splits {ops.gemm_plan(M, N, K)[1]}")
     print(f"M={M} N={N} K={K} f32={f32} bias={hb} res={hr}: bit-identical {same} relerr {err:.2e}{t}", flush=True)
     del bs
-L.mhdbg_set_gemm256_impl(-1)
+L.mh_set_option(b"gemm256_impl", 1)
 print("FAIL" if bad else "OK")
 sys.exit(1 if bad else 0)

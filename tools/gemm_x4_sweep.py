@@ -5,6 +5,7 @@ one-round grid (4096 x 4096 outputs = 256 tiles).  Variants with `ko` compute wr
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import os as _os; _os.environ.setdefault("MYRIAD_HIP_DEBUG_LIB", "1")   # the mhdbg_* hooks live in libmyriad_hip_dbg.so
 from myriad_amd import ops, _lib
 L = _lib.load()
 dev = torch.device("cuda:0")
@@ -33,9 +34,9 @@ for (M, N, K) in SHAPES + [(4096, 4096, k) for k in KS]:
     a = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16)
     bs = [(torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16) for _ in range(nb)]
     out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
-    L.mhdbg_set_gemm256_impl(0)
+    L.mh_set_option(b"gemm256_impl", 0)
     data[(M, N, K, -1)] = timeit(a, bs, out)
-    L.mhdbg_set_gemm256_impl(1)
+    L.mh_set_option(b"gemm256_impl", 1)
     for v in range(nv):
         L.mhdbg_set_gemm_x4_variant(v)
         data[(M, N, K, v)] = timeit(a, bs, out)
@@ -46,7 +47,7 @@ for (M, N, K) in SHAPES + [(4096, 4096, k) for k in KS]:
             data[(M, N, K, 100 + v)] = timeit(a, bs, out)
         L.mhdbg_set_gemm_x4_same_panel(0)
     del bs
-L.mhdbg_set_gemm_x4_variant(0); L.mhdbg_set_gemm256_impl(-1)
+L.mhdbg_set_gemm_x4_variant(0); L.mh_set_option(b"gemm256_impl", 1)
 hdr = "| variant | " + " | ".join(f"{m}x{n}x{k}" for (m, n, k) in SHAPES) + " | us / k-tile (64) | fixed us |"
 print(hdr); print("|" + "---|" * (len(SHAPES) + 3))
 rows = list(range(-1, nv)) + ([100 + v for v in range(nv)] if "--same-panel" in sys.argv else [])

@@ -5,6 +5,7 @@ really ran at.  One workgroup alone, a quarter / half / all of the chip, and the
 import sys, os, ctypes
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+import os as _os; _os.environ.setdefault("MYRIAD_HIP_DEBUG_LIB", "1")   # the mhdbg_* hooks live in libmyriad_hip_dbg.so
 from myriad_amd import ops, _lib
 L = _lib.load()
 L.mhdbg_set_gemm_x4_clock_probe.argtypes = [ctypes.c_void_p]

@@ -1,5 +1,6 @@
 import sys; sys.path.insert(0, "/root/repo")
 import torch
+import os as _os; _os.environ.setdefault("MYRIAD_HIP_DEBUG_LIB", "1")   # the mhdbg_* hooks live in libmyriad_hip_dbg.so
 from myriad_amd import ops, _lib
 L = _lib.load(); dev = torch.device("cuda:0"); ops.ensure_workspace(dev)
 M, N, K = 2056, 1408, 1408

@@ -3,7 +3,7 @@
 // border (myriad_amd/lora.py); these wavefront-primitive kernels do the skinny parts without materialising the
 // dropout mask, transposes or [M,4096] temporaries:
 //   lora_down : border[m, j] = s * sum_d keep(m,d) x[m,d] A[j,d]                  (block-per-row reductions)
-//   lora_dx   : dxn[m,d] = dx_base[m,d] + keep(m,d) * s * sum_j dborder[m,j] A[j,d]   (elementwise, A from L2)
+//   lora_dx   : dxn[m,d] = dx_base[m,d] + keep(m,d) * s * sum_j dborder[m,j] bf16(A[j,d])   (elementwise; the forward multiplied by bf16(A))
 //   lora_wgrad: dA[j,d] = sum_m s dborder[m,j] keep(m,d) x[m,d] ; dB_q[d,j] = sum_m dq[m,d] border[m,j] ; dB_v likewise
 //               (thread-per-column partial sums over row chunks + fixed-order reduce: deterministic)
 //   lora_refresh_border: writes bf16(B_q), bf16(B_v) into the borders of W_ext and W_ext^T.
@@ -11,6 +11,7 @@
 // peft gives q_proj and v_proj their own nn.Dropout, i.e. independent masks: rows j < r of A (q) see keep(seed, .), rows
 // j >= r (v) see the second draw of the same hash (seed with bit 63 set; common.h dropout_keep_pair).
 #include "common.h"
+#include <stdlib.h>
 
 // The 64-column border holds G = 64 / R2 GROUPS of R2 columns.  lora_down splits D into G ranges, one workgroup column per
 // range, and writes each range's partial product into its own group; the weight border repeats [B_q | B_v] G times, so the qkv
@@ -117,9 +118,13 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(const void* __restrict__ d
   const float ik = 1.f / (1.f - p);
   const int d = (blockIdx.x * 256 + threadIdx.x) * 4;
   if (d >= D) return;
-  float4_t a[R2];
+  float4_t a[R2];                                  // rounded to bf16: the A the forward's LoRA-down product multiplied by
 #pragma unroll
-  for (int j = 0; j < R2; ++j) a[j] = *reinterpret_cast<const float4_t*>(A + (long)j * D + d);
+  for (int j = 0; j < R2; ++j) {
+    a[j] = *reinterpret_cast<const float4_t*>(A + (long)j * D + d);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) a[j][e] = bf2f(f2bf(a[j][e]));
+  }
   const int m0 = blockIdx.y * rows_per;
   const int m1 = (m0 + rows_per) < M ? (m0 + rows_per) : M;
   for (int m = m0; m < m1; ++m) {
@@ -174,27 +179,34 @@ __global__ __launch_bounds__(256) void lora_dx_kernel(const void* __restrict__ d
 
 // lora_dx and the RMSNorm backward that consumes it (the layer's input norm, modeling_llama.py:66-74 under autograd) as ONE
 // kernel: the [M, D] fp32 d(xn) that lora_dx wrote and rmsnorm_bwd_kernel read back never exists, and one dependent launch
-// leaves the LLaMA backward chain per layer.  A workgroup owns LXN_ROWS token rows and walks D in chunks of 1024 columns (256
-// threads x 4): a thread loads ITS four columns of all R2 rows of A once per chunk and uses them for every row (A is read once
-// per workgroup from L2, not once per row), the rows' x and d(xn) values stay in registers between the row sums and the output
-// pass.  Same expressions (common.h: lora_dx_value / rms_bwd_sums / rms_bwd_value), same per-thread column sets, same
-// summation orders and the same 4-wave block reduction as lora_dx_kernel followed by rmsnorm_bwd_kernel: the results are
-// bit-identical to the two launches (tests/test_model_gpu.py).
-#define LXN_ROWS 4
-#define LXN_NCH 4            // D <= 4096
-template <int R2, int sbf>
-__global__ __launch_bounds__(256, 2) void lora_dx_rmsnorm_bwd_kernel(
+// leaves the LLaMA backward chain per layer.
+// Shape of the kernel: a 1024-thread workgroup (16 waves, one per CU) owns ROWS token rows; thread T owns columns 4T..4T+3 of
+// every row, so ITS four columns of all R2 rows of A sit in 64 registers, loaded once per workgroup (a one-row-per-workgroup
+// form re-reads the 256 KiB of A for every row: 300 MB of L2 traffic, measured 44 us; a 256-thread workgroup with four rows
+// in registers has too few waves per CU to keep HBM busy, measured 55 us; the two separate launches 21.8 + 19.9 us).
+// Bit-identical to lora_dx_kernel followed by rmsnorm_bwd_kernel: the same expressions (common.h: lora_dx_value / rms_bwd_sums /
+// rms_bwd_value) and the SAME summation order -- rmsnorm_bwd_kernel's thread t adds its chunks c = 0..3 (columns c * 1024 + 4t..)
+// one after the other, then a wave butterfly, then the four wave sums in order; here chunk c of that thread is thread
+// c * 256 + t, so the running sums are handed from wave group c to c + 1 through LDS (three hand-offs for all rows at once)
+// and group 3 finishes with the same butterfly and the same four-term sum.
+#define LXN_NT 1024
+template <int R2, int sbf, int ROWS>
+__global__ __launch_bounds__(LXN_NT) void lora_dx_rmsnorm_bwd_kernel(
     const void* __restrict__ dx_ext, long ld, int nslab, long slab, const float* __restrict__ A, const float* __restrict__ x,
     const float* __restrict__ w, const float* dres, float* dx, bf16_t* dx_bf, float* __restrict__ border_out, int M, int D,
     float s, float p, unsigned long long seed, float eps) {
-  __shared__ float s_g[LXN_ROWS][R2];
-  __shared__ float s_red[2 * LXN_ROWS][4];
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int m0 = blockIdx.x * LXN_ROWS;
+  __shared__ float s_g[ROWS][R2];
+  __shared__ float2 s_chain[ROWS][256];
+  __shared__ float s_red[2 * ROWS][4];
+  __shared__ float4_t s_dxn[ROWS][LXN_NT];                     // 16 KiB per row
+  const int T = threadIdx.x, lane = T & 63, wave = T >> 6, grp = T >> 8, t = T & 255;
+  const int d = T * 4;
+  const bool live = d < D;
+  const int m0 = blockIdx.x * ROWS;
   const float ik = 1.f / (1.f - p);
   // d(s*t): the R2 border values of each row, summed over the slabs in slab order
-  if (t < LXN_ROWS * R2) {
-    const int r = t / R2, j = t - r * R2, m = m0 + r;
+  if (T < ROWS * R2) {
+    const int r = T / R2, j = T - r * R2, m = m0 + r;
     float g = 0.f;
     if (m < M) {
       for (int k = 0; k < nslab; ++k) {
@@ -205,97 +217,153 @@ __global__ __launch_bounds__(256, 2) void lora_dx_rmsnorm_bwd_kernel(
     }
     s_g[r][j] = g;
   }
-  __syncthreads();
-  float4_t xv[LXN_ROWS][LXN_NCH], gv[LXN_ROWS][LXN_NCH];
-  float ss[LXN_ROWS], dot[LXN_ROWS];
+  // Register budget: 16 waves per workgroup leave 128 registers per thread.  A is held as packed bf16 pairs (32 registers for
+  // 16 x 4 values) -- the values lora_dx_kernel multiplies by: the dx correction uses the bf16-rounded A the forward's
+  // LoRA-down product multiplied by.  The rows' x values and slabs are all requested before the first is used.
+  float4_t ww = (float4_t){0.f, 0.f, 0.f, 0.f};
+  float4_t xv[ROWS], gv[ROWS];
+  if (live) {
 #pragma unroll
-  for (int r = 0; r < LXN_ROWS; ++r) ss[r] = dot[r] = 0.f;
+    for (int r = 0; r < ROWS; ++r) {
+      const int m = (m0 + r) < M ? (m0 + r) : (M - 1);        // rows past M redo the last row; nothing of theirs is stored
+      xv[r] = *reinterpret_cast<const float4_t*>(x + (long)m * D + d);
+    }
+    ww = *reinterpret_cast<const float4_t*>(w + d);
+    // The LoRA pass walks the rows in a real loop (unrolled, the compiler interleaves all rows and spills 150 registers) with the
+    // slabs of the next two rows in flight, and parks each row's d(xn) in LDS.
+    float4_t nb0[3], nb1[3];
+    auto slab_req = [&](int r, int k) -> float4_t {
+      const int m = (m0 + r) < M ? (m0 + r) : (M - 1);
+      return slab_load4(dx_ext, (long)m * ld + (long)k * slab + d, sbf);
+    };
 #pragma unroll
-  for (int c = 0; c < LXN_NCH; ++c) {
-    const int d = c * 1024 + t * 4;
-    if (d < D) {
-      float4_t a[R2];
+    for (int k = 0; k < 3; ++k) {
+      nb0[k] = k < nslab ? slab_req(0, k) : (float4_t){0.f, 0.f, 0.f, 0.f};
+      nb1[k] = (k < nslab && ROWS > 1) ? slab_req(1, k) : (float4_t){0.f, 0.f, 0.f, 0.f};
+    }
+    asm volatile("" ::: "memory");                             // ... in flight before A: 32 CUs per XCD queue on the same L2 lines there
+    uint2 apk[R2];
 #pragma unroll
-      for (int j = 0; j < R2; ++j) a[j] = *reinterpret_cast<const float4_t*>(A + (long)j * D + d);
-      const float4_t ww = *reinterpret_cast<const float4_t*>(w + d);
+    for (int h2 = 0; h2 < 2; ++h2) {                           // two batches of loads: 32 transient registers, not 64
 #pragma unroll
-      for (int r = 0; r < LXN_ROWS; ++r) {
-        const int m = (m0 + r) < M ? (m0 + r) : (M - 1);      // rows past M redo the last row; nothing of theirs is stored
-        const long r0 = (long)m * ld;
-        float4_t base = (float4_t){0.f, 0.f, 0.f, 0.f};
-        for (int k = 0; k < nslab; ++k) {
-          const float4_t bk = slab_load4(dx_ext, r0 + (long)k * slab + d, sbf);
-          base[0] += bk[0]; base[1] += bk[1]; base[2] += bk[2]; base[3] += bk[3];
-        }
-        const float4_t v = *reinterpret_cast<const float4_t*>(x + (long)m * D + d);
-        float4_t acc = (float4_t){0.f, 0.f, 0.f, 0.f}, accv = (float4_t){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int j = 0; j < R2 / 2; ++j) {
-          const float g = s_g[r][j];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] = __builtin_fmaf(g, a[j][e], acc[e]);
-        }
-#pragma unroll
-        for (int j = R2 / 2; j < R2; ++j) {
-          const float g = s_g[r][j];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) accv[e] = __builtin_fmaf(g, a[j][e], accv[e]);
-        }
-        float4_t o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float kq, kv;
-          dropout_keep_pair(seed, (unsigned long long)((long)m * D + d + e), p, ik, kq, kv);
-          o[e] = lora_dx_value(base[e], s, acc[e], kq, accv[e], kv);
-          rms_bwd_sums(v[e], ww[e], o[e], ss[r], dot[r]);
-        }
-        xv[r][c] = v;
-        gv[r][c] = o;
+      for (int j = h2 * (R2 / 2); j < (h2 + 1) * (R2 / 2); ++j) {
+        const float4_t af = *reinterpret_cast<const float4_t*>(A + (long)j * D + d);
+        apk[j].x = pack_bf2(af[0], af[1]);
+        apk[j].y = pack_bf2(af[2], af[3]);
       }
+      asm volatile("" ::: "memory");
+    }
+    __syncthreads();                                           // s_g
+#pragma unroll 1
+    for (int r = 0; r < ROWS; ++r) {
+      const int m = (m0 + r) < M ? (m0 + r) : (M - 1);
+      float4_t base = (float4_t){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (k < nslab) { base[0] += nb0[k][0]; base[1] += nb0[k][1]; base[2] += nb0[k][2]; base[3] += nb0[k][3]; }
+      for (int k = 3; k < nslab; ++k) {                        // more than three slabs (small M): in order, as they come
+        const float4_t bk = slab_req(r, k);
+        base[0] += bk[0]; base[1] += bk[1]; base[2] += bk[2]; base[3] += bk[3];
+      }
+#pragma unroll
+      for (int k = 0; k < 3; ++k) {
+        nb0[k] = nb1[k];
+        if (k < nslab && r + 2 < ROWS) nb1[k] = slab_req(r + 2, k);
+      }
+      float4_t acc = (float4_t){0.f, 0.f, 0.f, 0.f}, accv = (float4_t){0.f, 0.f, 0.f, 0.f};
+      unsigned hi, sh;                                         // 0xffff0000 and 16 the compiler cannot see through: the unpack of A is
+      asm volatile("v_mov_b32 %0, 0xffff0000\n\tv_mov_b32 %1, 16" : "=v"(hi), "=v"(sh));   // redone per row, not hoisted out of
+#pragma unroll                                                 // the loop into 64 more registers
+      for (int j = 0; j < R2; ++j) {
+        const float g = s_g[r][j];
+        const float a0 = __uint_as_float(apk[j].x << sh), a1 = __uint_as_float(apk[j].x & hi);
+        const float a2 = __uint_as_float(apk[j].y << sh), a3 = __uint_as_float(apk[j].y & hi);
+        if (j < R2 / 2) {
+          acc[0] = __builtin_fmaf(g, a0, acc[0]); acc[1] = __builtin_fmaf(g, a1, acc[1]);
+          acc[2] = __builtin_fmaf(g, a2, acc[2]); acc[3] = __builtin_fmaf(g, a3, acc[3]);
+        } else {
+          accv[0] = __builtin_fmaf(g, a0, accv[0]); accv[1] = __builtin_fmaf(g, a1, accv[1]);
+          accv[2] = __builtin_fmaf(g, a2, accv[2]); accv[3] = __builtin_fmaf(g, a3, accv[3]);
+        }
+      }
+      float4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float kq, kv;
+        dropout_keep_pair(seed, (unsigned long long)((long)m * D + d + e), p, ik, kq, kv);
+        o[e] = lora_dx_value(base[e], s, acc[e], kq, accv[e], kv);     // = d(xn), what lora_dx_kernel stores
+      }
+      s_dxn[r][T] = o;
+    }
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) gv[r] = s_dxn[r][T];        // each thread reads back its own values: no barrier needed
+  } else {
+    __syncthreads();
+  }
+  // the residual gradient of the output pass is requested now: it lands while the row sums are handed from group to group
+  float4_t dd[ROWS];
+  if (live && dres) {
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const long m = (m0 + r) < M ? (m0 + r) : (M - 1);
+      dd[r] = *reinterpret_cast<const float4_t*>(dres + m * D + d);
     }
   }
-  // the block reductions of rmsnorm_bwd_kernel (wave butterfly, then the four wave sums added in wave order), all rows at once
+  // row sums in rmsnorm_bwd_kernel's order: wave group c continues the running sums of group c - 1
+  float ss[ROWS], dot[ROWS];
 #pragma unroll
-  for (int r = 0; r < LXN_ROWS; ++r) {
-    const float a = wave_sum(ss[r]), b = wave_sum(dot[r]);
-    if (lane == 0) { s_red[2 * r][wave] = a; s_red[2 * r + 1][wave] = b; }
+  for (int r = 0; r < ROWS; ++r) ss[r] = dot[r] = 0.f;
+#pragma unroll
+  for (int h = 0; h < 4; ++h) {
+    if (grp == h) {
+      if (h > 0) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) { const float2 c2 = s_chain[r][t]; ss[r] = c2.x; dot[r] = c2.y; }
+      }
+      if (live) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) rms_bwd_sums(xv[r][e], ww[e], gv[r][e], ss[r], dot[r]);
+      }
+      if (h < 3) {
+#pragma unroll
+        for (int r = 0; r < ROWS; ++r) s_chain[r][t] = make_float2(ss[r], dot[r]);
+      }
+    }
+    if (h < 3) __syncthreads();
+  }
+  if (grp == 3) {
+#pragma unroll
+    for (int r = 0; r < ROWS; ++r) {
+      const float sa = wave_sum(ss[r]), sb = wave_sum(dot[r]);
+      if (lane == 0) { s_red[2 * r][wave - 12] = sa; s_red[2 * r + 1][wave - 12] = sb; }
+    }
   }
   __syncthreads();
+  if (!live) return;
 #pragma unroll
-  for (int r = 0; r < LXN_ROWS; ++r) {
-    float a = 0.f, b = 0.f;
+  for (int r = 0; r < ROWS; ++r) {
+    const long m = m0 + r;
+    if (m < M) {
+      float sa = 0.f, sb = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { a += s_red[2 * r][i]; b += s_red[2 * r + 1][i]; }
-    ss[r] = a;
-    dot[r] = b;
-  }
+      for (int i = 0; i < 4; ++i) { sa += s_red[2 * r][i]; sb += s_red[2 * r + 1][i]; }
+      const float rr = rsqrtf(sa / D + eps);
+      const float cc = rr * rr * rr * sb / D;
+      float4_t o;
 #pragma unroll
-  for (int c = 0; c < LXN_NCH; ++c) {
-    const int d = c * 1024 + t * 4;
-    if (d < D) {
-      const float4_t ww = *reinterpret_cast<const float4_t*>(w + d);
+      for (int e = 0; e < 4; ++e) o[e] = rms_bwd_value(rr, ww[e], gv[r][e], xv[r][e], cc);
+      if (dres) {
 #pragma unroll
-      for (int r = 0; r < LXN_ROWS; ++r) {
-        const long m = m0 + r;
-        if (m < M) {
-          const float rr = rsqrtf(ss[r] / D + eps);
-          const float cc = rr * rr * rr * dot[r] / D;
-          float4_t o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = rms_bwd_value(rr, ww[e], gv[r][c][e], xv[r][c][e], cc);
-          if (dres) {
-            const float4_t dd = *reinterpret_cast<const float4_t*>(dres + m * D + d);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] += dd[e];
-          }
-          if (dx) *reinterpret_cast<float4_t*>(dx + m * D + d) = o;
-          if (dx_bf) {
-            uint2 pk;
-            pk.x = pack_bf2(o[0], o[1]);
-            pk.y = pack_bf2(o[2], o[3]);
-            *reinterpret_cast<uint2*>(dx_bf + m * D + d) = pk;
-          }
-        }
+        for (int e = 0; e < 4; ++e) o[e] += dd[r][e];
+      }
+      if (dx) *reinterpret_cast<float4_t*>(dx + m * D + d) = o;
+      if (dx_bf) {
+        uint2 pk;
+        pk.x = pack_bf2(o[0], o[1]);
+        pk.y = pack_bf2(o[2], o[3]);
+        *reinterpret_cast<uint2*>(dx_bf + m * D + d) = pk;
       }
     }
   }
@@ -504,15 +572,27 @@ int mh_launch_lora_dx_rmsnorm_bwd(const void* dx_ext, int slab_bf16, long ld, in
                                   int R2_, float s, float p, unsigned long long seed, float eps, hipStream_t stream) {
   if (M <= 0) return MH_OK;
   if (D % 4 || ld % 4 || ld < D + R2_ || p < 0.f || p >= 1.f || nslab < 1 || R2_ > 64) return MH_ERR_ARG;
-  if (D > 1024 * LXN_NCH) return MH_ERR_UNSUPPORTED;
-  const dim3 grid((M + LXN_ROWS - 1) / LXN_ROWS);
-  if (R2_ != 16) return MH_ERR_UNSUPPORTED;          // r = 8 (the shipped config); r = 16 would spill its 128 registers of A
-  if (slab_bf16)
-    hipLaunchKernelGGL((lora_dx_rmsnorm_bwd_kernel<16, 1>), grid, dim3(256), 0, stream, dx_ext, ld, nslab, slab, A, x, w, dres, dx,
-                       (bf16_t*)dx_bf16, border_out, M, D, s, p, seed, eps);
-  else
-    hipLaunchKernelGGL((lora_dx_rmsnorm_bwd_kernel<16, 0>), grid, dim3(256), 0, stream, dx_ext, ld, nslab, slab, A, x, w, dres, dx,
-                       (bf16_t*)dx_bf16, border_out, M, D, s, p, seed, eps);
+  if (D > 4 * LXN_NT) return MH_ERR_UNSUPPORTED;
+  if (R2_ != 16) return MH_ERR_UNSUPPORTED;          // r = 8 (the shipped config); r = 16 would need 128 registers of A per thread
+  // rows per workgroup: as few as give one round of <= 256 workgroups (A is read once per workgroup), five at most
+  int rows = M <= 256 ? 1 : (M <= 512 ? 2 : (M <= 768 ? 3 : (M <= 1024 ? 4 : 5)));
+#ifdef MH_DEBUG_HOOKS
+  { const char* e = getenv("MYRIAD_LXN_ROWS"); if (e && atoi(e) >= 1 && atoi(e) <= 5) rows = atoi(e); }
+#endif
+#define LXN_LAUNCH(SBF, ROWS)                                                                                                   \
+  hipLaunchKernelGGL((lora_dx_rmsnorm_bwd_kernel<16, SBF, ROWS>), dim3((M + ROWS - 1) / ROWS), dim3(LXN_NT), 0, stream, dx_ext, ld,  \
+                     nslab, slab, A, x, w, dres, dx, (bf16_t*)dx_bf16, border_out, M, D, s, p, seed, eps)
+#define LXN_ROWS_SWITCH(SBF)                                                                          \
+  switch (rows) {                                                                                     \
+    case 1: LXN_LAUNCH(SBF, 1); break;                                                                \
+    case 2: LXN_LAUNCH(SBF, 2); break;                                                                \
+    case 3: LXN_LAUNCH(SBF, 3); break;                                                                \
+    case 4: LXN_LAUNCH(SBF, 4); break;                                                                \
+    default: LXN_LAUNCH(SBF, 5); break;                                                               \
+  }
+  if (slab_bf16) { LXN_ROWS_SWITCH(1) } else { LXN_ROWS_SWITCH(0) }
+#undef LXN_ROWS_SWITCH
+#undef LXN_LAUNCH
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

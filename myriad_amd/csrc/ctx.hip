@@ -43,6 +43,14 @@ struct mh_ctx {
 static void* open_rccl() {
   static void* handle = nullptr;
   if (handle) return handle;
+  // MYRIAD_RCCL_LIB=<path>: that image and no other (a site-specific RCCL build; the two-ranks-on-one-GPU test's stand-in,
+  // tests/fake_rccl) -- no fallback to the search path when it cannot be loaded: the caller then sees MH_ERR_UNSUPPORTED
+  if (const char* forced = getenv("MYRIAD_RCCL_LIB")) {
+    if (forced[0]) {
+      handle = dlopen(forced, RTLD_NOW | RTLD_LOCAL | RTLD_NODELETE);
+      return handle;
+    }
+  }
   const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so"};
   // a host framework that already brought an RCCL into the process (PyTorch-ROCm ships its own): use THAT image -- one
   // bootstrap, one set of IPC handles per process -- before loading another copy from the search path

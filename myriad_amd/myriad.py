@@ -50,6 +50,16 @@ def module_of(name: str) -> str:
     raise KeyError(name)
 
 
+
+def accum_update_due(calls_since_update: int, accum_grad_iters: int, accum_index=None) -> bool:
+    """Whether the optimiser steps after this backward (base_task.py:262-271).  With the iteration index of the epoch the
+    reference's rule `(i + 1) % accum_grad_iters == 0`; without it, every accum_grad_iters-th call."""
+    n = max(int(accum_grad_iters), 1)
+    if accum_index is not None:
+        return (int(accum_index) + 1) % n == 0
+    return calls_since_update >= n
+
+
 class ParamStore:
     """All trainable parameters in ONE flat fp32 buffer (+ grad, Adam m, v): a single RCCL all-reduce and a handful of
     fused AdamW launches per step.  Layout: [weight-decay group | no-decay group | per-module use flags]; inside each
@@ -739,7 +749,7 @@ class MyriadHIP(nn.Module):
         return out
 
     def train_step(self, samples, lr: float, weight_decay: float = 0.05, allreduce=None, world: int = 1, dp=None,
-                   overlap: bool = True, next_samples=None, accum_grad_iters: int = 1):
+                   overlap: bool = True, next_samples=None, accum_grad_iters: int = 1, accum_index=None):
         """forward + backward (+ gradient all-reduce) + fused AdamW: one optimisation step of
         `BaseTask._train_inner_loop` (base_task.py:233-271) without the autograd bridge.
         With a `DataParallel` (`dp`) and overlap=True the all-reduce + AdamW of step t are hidden behind the frozen
@@ -750,8 +760,11 @@ class MyriadHIP(nn.Module):
         that many consecutive calls are summed in the flat buffer (no division, as the reference); the exchange and the AdamW
         run on the last call of a window, with that call's lr.  A module is skipped by the gated AdamW only if no call of the
         window (on any rank) used it, which is what `optimizer.zero_grad()` (set_to_none) + DDP leave torch's AdamW.  The
-        reference all-reduces every backward; one exchange of the window's sum is the same gradient.  A window left open at
-        the end of an epoch carries into the next one, as the reference's un-zeroed .grad does."""
+        reference all-reduces every backward; one exchange of the window's sum is the same gradient.
+        `accum_index` = the iteration index inside the epoch (RunnerBase passes it): the update then lands where the reference
+        puts it, `(i + 1) % accum_grad_iters == 0` with i restarting every epoch (base_task.py:265), so when iters_per_epoch is
+        not a multiple of accum_grad_iters the left-over gradients of an epoch's tail are folded into the next epoch's first
+        update, as the reference's un-zeroed .grad does.  Without it the window is counted in calls."""
         with torch.no_grad():
             vit_out = self._take_prefetched_vit(samples)
             if next_samples is not None:
@@ -764,9 +777,9 @@ class MyriadHIP(nn.Module):
                 vit_out = self.visual_encoder.forward(self._image_of(samples))
                 self.finish_update()
             loss = self._forward_impl(samples, True, vit_out=vit_out)
-            self.backward(accumulate=self._accum_count > 0)
+            self.backward(accumulate=self._accum_count > 0)      # > 0: the flat buffer holds gradients no update has consumed
             self._accum_count += 1
-            if self._accum_count < max(int(accum_grad_iters), 1):
+            if not accum_update_due(self._accum_count, accum_grad_iters, accum_index):
                 return loss                                   # inside an accumulation window: no exchange, no update
             self._accum_count = 0
             if dp is not None and dp.world > 1 and overlap:

@@ -73,27 +73,54 @@ class CtxCollective:
     DT = {torch.float32: 0, torch.bfloat16: 1}
 
     def __init__(self, device, rank: int, world: int, dist=None):
+        """Collective: every rank of `dist` must call this together.  Raises on EVERY rank if any rank could not create its
+        context or rank 0 could not produce a communicator id -- the ranks agree on that through the process group BEFORE anyone
+        enters mh_ctx_comm_init (ncclCommInitRank is a rendezvous: a rank that skipped it would leave the others inside it),
+        and every rank runs the same sequence of process-group collectives on every path."""
         import ctypes
         from . import _lib
         self.lib, self.check = _lib.load(), _lib.check
         self.dev = torch.device(device)
-        h = ctypes.c_void_p()
-        with torch.cuda.device(self.dev):                 # the context's side stream and events belong to THIS device
-            self.check(self.lib.mh_ctx_create(ctypes.addressof(h)), "mh_ctx_create")
-        self.h = h
         self.world = world
-        idbuf = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
+        self.h = None
+        err = None
+        h = ctypes.c_void_p()
+        try:
+            with torch.cuda.device(self.dev):             # the context's side stream and events belong to THIS device (ADVICE r3)
+                self.check(self.lib.mh_ctx_create(ctypes.addressof(h)), "mh_ctx_create")
+            self.h = h
+        except Exception as e:                            # noqa: BLE001
+            err = e
+        msg = torch.zeros(129, dtype=torch.uint8)         # [communicator id (128) | rank 0's "id is valid" flag]
+        if rank == 0 and err is None:
             raw = (ctypes.c_ubyte * 128)()
-            self.check(self.lib.mh_ctx_comm_id(ctypes.addressof(raw)), "mh_ctx_comm_id")
-            idbuf = torch.tensor(list(raw), dtype=torch.uint8)
+            try:
+                self.check(self.lib.mh_ctx_comm_id(ctypes.addressof(raw)), "mh_ctx_comm_id")
+                msg[:128] = torch.tensor(list(raw), dtype=torch.uint8)
+                msg[128] = 1
+            except Exception as e:                        # noqa: BLE001
+                err = e
         if world > 1:
-            t = idbuf.to(self.dev) if dist.get_backend() == "nccl" else idbuf
+            on_dev = dist.get_backend() == "nccl"
+            t = msg.to(self.dev) if on_dev else msg
             dist.broadcast(t, src=0)
-            idbuf = t.cpu()
-        raw = (ctypes.c_ubyte * 128)(*idbuf.tolist())
-        with torch.cuda.device(self.dev):
-            self.check(self.lib.mh_ctx_comm_init(self.h, ctypes.addressof(raw), rank, world), "mh_ctx_comm_init")
+            msg = t.cpu()
+            ok = torch.tensor([1.0 if (err is None and int(msg[128]) == 1) else 0.0])
+            ok = ok.to(self.dev) if on_dev else ok
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            all_ok = float(ok.item()) == 1.0
+        else:
+            all_ok = err is None and int(msg[128]) == 1
+        if not all_ok:
+            self.close()
+            raise RuntimeError(f"mh_ctx bring-up failed on at least one rank (this rank: {err if err is not None else 'ok'})")
+        raw = (ctypes.c_ubyte * 128)(*msg[:128].tolist())
+        try:
+            with torch.cuda.device(self.dev):
+                self.check(self.lib.mh_ctx_comm_init(self.h, ctypes.addressof(raw), rank, world), "mh_ctx_comm_init")
+        except Exception:
+            self.close()
+            raise
 
     @staticmethod
     def _s():
@@ -118,7 +145,7 @@ class CtxCollective:
         self.check(self.lib.mh_allreduce_wait(self.h, self._s()), "mh_allreduce_wait")
 
     def close(self) -> None:
-        if self.h is not None:
+        if getattr(self, "h", None) is not None:
             self.lib.mh_ctx_destroy(self.h)
             self.h = None
 
@@ -164,7 +191,8 @@ class DataParallel:
         self.ctx = None
         self._gloo = dist.is_initialized() and dist.get_backend() == "gloo"
         want = os.environ.get("MYRIAD_DP_COLLECTIVE", "ctx" if (dist.is_initialized() and dist.get_backend() == "nccl") else "torch")
-        if want == "ctx" and self.world > 1 and device is not None and torch.device(device).type == "cuda" and not self._gloo:
+        explicit = os.environ.get("MYRIAD_DP_COLLECTIVE") == "ctx"      # asked for by name: also beside a gloo process group (tests)
+        if want == "ctx" and self.world > 1 and device is not None and torch.device(device).type == "cuda" and (explicit or not self._gloo):
             try:
                 ctx = CtxCollective(device, self.rank, self.world, dist)
                 probe = torch.ones(8, dtype=torch.float32, device=device)
@@ -180,7 +208,7 @@ class DataParallel:
                 self.ctx = None
             # the choice has to be the same on every rank (a rank on torch.distributed and a rank on the context would wait for
             # each other forever): agree through the process group, fall back everywhere if anyone fell back
-            ok = torch.tensor([1.0 if self.ctx is not None else 0.0], device=device)
+            ok = torch.tensor([1.0 if self.ctx is not None else 0.0], device=None if self._gloo else device)
             dist.all_reduce(ok, op=dist.ReduceOp.MIN)
             if float(ok.item()) == 0.0 and self.ctx is not None:
                 self.ctx.close()
@@ -271,11 +299,14 @@ class DataParallel:
         verbs, which queue on the context's side stream; what has to happen after the wait is kept in self._pending."""
         ctx, bf = self.ctx, self.grad_dtype == torch.bfloat16
         after = []
+        from . import ops
         if self.mode == "allreduce":
             if bf:
-                w = self._cast(flat_g_comm, torch.bfloat16)
+                # the wire copy lives in a persistent buffer: the verb reads it on the context's side stream, which torch's
+                # caching allocator knows nothing about -- a per-step tensor could be handed out again while RCCL still reads it
+                w = ops.to_bf16(flat_g_comm, out=self._persistent("ar_wire", flat_g_comm.numel(), torch.bfloat16, flat_g_comm.device))
                 ctx.start(w)
-                after.append(lambda: flat_g_comm.copy_(self._cast(w, torch.float32)))
+                after.append(lambda: ops.to_f32(w, out=flat_g_comm))
             else:
                 ctx.start(flat_g_comm)
         else:
@@ -288,7 +319,10 @@ class DataParallel:
             else:
                 padded = self._persistent("rs_pad", per * self.world, body.dtype, body.device)
                 padded[:n_grad].copy_(body)
-            w = self._cast(padded, self.grad_dtype)
+            if bf:      # persistent wire buffer (a per-step cast result was freed while the side stream still read it)
+                w = ops.to_bf16(padded, out=self._persistent("rs_wire", padded.numel(), torch.bfloat16, padded.device))
+            else:
+                w = padded
             mine = self._persistent("rs_mine", per, w.dtype, w.device)
             ctx.reduce_scatter(w, mine)
             after.append(lambda: body[lo:hi].copy_(self._cast(mine, body.dtype)[:hi - lo]))
@@ -538,7 +572,7 @@ class RunnerBase:
             lr = sched.step(cur_epoch=epoch, cur_step=i)                                    # stepped BEFORE the forward (:229)
             nxt = next(loader) if i + 1 < iters else None                                   # one batch of lookahead: its frozen
             loss = model.train_step(samples, lr, wd, dp=self.dp, next_samples=nxt,          # ViT forward runs on a side stream
-                                    accum_grad_iters=self.accum_grad_iters)
+                                    accum_grad_iters=self.accum_grad_iters, accum_index=i)
             pending.append(loss)                          # the reference reads loss.item() every step (:276), which stalls the
             meters["lr"].update(lr)                       # launch thread behind the GPU; here the values are fetched at log points
             if i % self.log_freq == 0 or i == iters - 1:

@@ -15,15 +15,38 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _reference(dev):
+def _wire_sum(g0, g1, wire, n_grad=None):
+    """What the exchange hands back for two ranks' buffers: the plain fp32 sum, or with a bf16 wire each rank's buffer rounded
+    to bf16, added in fp32 and rounded to bf16 once more (what RCCL's bf16 sum and the stand-in do); with n_grad only the
+    first n_grad elements travel in bf16 (rs_ag: the use flags behind them are all-reduced in fp32)."""
+    if wire != "bf16":
+        return g0 + g1
+    def rt(t):
+        return t.to(torch.bfloat16).float()
+    out = g0 + g1
+    n = out.numel() if n_grad is None else n_grad
+    out[:n] = rt(rt(g0[:n]) + rt(g1[:n]))
+    return out
+
+
+@pytest.fixture(scope="module")
+def fake_rccl(tmp_path_factory):
+    """The stand-in RCCL of tests/fake_rccl, built once per session with hipcc (host code only)."""
+    out = str(tmp_path_factory.mktemp("fake_rccl") / "libfake_rccl.so")
+    src = os.path.join(ROOT, "tests", "fake_rccl", "fake_rccl.cpp")
+    subprocess.check_call([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O2", "-shared", "-fPIC", "-o", out, src])
+    return out
+
+
+def _reference(dev, wire="f32", mode="allreduce"):
     """One process: per step, run both ranks' forward + backward (their batch, their prompt stage, their dropout seed), add the
-    two [gradients | use flags] buffers, one gated AdamW with grad_scale = 1/2."""
+    two [gradients | use flags] buffers (as the wire would), one gated AdamW with grad_scale = 1/2."""
     from tests import dp_common as C
     model, cfg = C.build_model(dev)
     st = model.store
     losses = {0: [], 1: []}
     for i in range(C.N_STEPS):
-        gsum = None
+        gs = []
         for r in (0, 1):
             model.lora.base_seed = C.BASE_SEED + r
             model.lora.step_seed = i                              # the training forward increments it: step i draws seed i + 1
@@ -34,20 +57,27 @@ def _reference(dev):
                 if model.use_lora:
                     model.lora.join_wgrads()
             torch.cuda.synchronize()
-            g = st.flat_g_comm.clone()
-            gsum = g if gsum is None else gsum + g
-        st.flat_g_comm.copy_(gsum)
+            gs.append(st.flat_g_comm.clone())
+        st.flat_g_comm.copy_(_wire_sum(gs[0], gs[1], wire, st.total if mode == "rs_ag" else None))
         st.adamw_step(C.LRS[i], 0.05, grad_scale=0.5)
     return C.snapshot(model), losses
 
 
-@pytest.mark.parametrize("mode", ["allreduce", "rs_ag"])
-def test_two_ranks_on_one_gpu_equal_one_process_summing_their_gradients(mode, tmp_path):
+CASES = [("allreduce", "torch", "f32"), ("rs_ag", "torch", "f32"),
+         # the path an 8-GPU node runs by default: the mh_ctx verbs, both modes, both wire types
+         ("allreduce", "ctx", "f32"), ("rs_ag", "ctx", "f32"), ("allreduce", "ctx", "bf16"), ("rs_ag", "ctx", "bf16"),
+         # rank 0 cannot bring its context up: no rank may enter the communicator rendezvous, all fall back to torch.distributed
+         ("allreduce", "ctx_bad0", "f32")]
+
+
+@pytest.mark.parametrize("mode,collective,wire", CASES)
+def test_two_ranks_on_one_gpu_equal_one_process_summing_their_gradients(mode, collective, wire, tmp_path, fake_rccl):
     from tests import dp_common as C
-    port = str(29600 + (os.getpid() % 200) + (0 if mode == "allreduce" else 7))
+    port = str(29600 + (os.getpid() % 200) + 7 * CASES.index((mode, collective, wire)))
     outs = [str(tmp_path / f"rank{r}.pt") for r in (0, 1)]
     env = dict(os.environ, PYTHONPATH=ROOT)
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), "2", port, mode, outs[r]],
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "dp_worker.py"), str(r), "2", port, mode, outs[r],
+                               collective, wire, fake_rccl],
                               env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in (0, 1)]
     logs = []
     for p in procs:
@@ -60,7 +90,7 @@ def test_two_ranks_on_one_gpu_equal_one_process_summing_their_gradients(mode, tm
         logs.append(o.decode(errors="replace")[-3000:])
     assert all(p.returncode == 0 for p in procs), "\n----\n".join(logs)
     s0, s1 = (torch.load(o) for o in outs)
-    ref, ref_losses = _reference(torch.device("cuda:0"))
+    ref, ref_losses = _reference(torch.device("cuda:0"), wire, mode)
     # the two ranks end with the same parameters and optimiser state
     for k in ("p", "m", "v"):
         assert torch.equal(s0[k], s1[k]), k

@@ -409,3 +409,29 @@ def test_config_reads_the_reference_yaml_files_unchanged(rel):
     assert len(cfg.datasets_cfg) >= 1
     d = cfg.to_dict()
     assert set(d) >= {"model", "run", "datasets"}
+
+
+def test_accum_grad_iters_follows_the_reference_schedule_across_epochs():
+    """base_task.py:262-271: the optimiser steps when (i + 1) % accum_grad_iters == 0 with i the index INSIDE the epoch, and
+    .grad is only zeroed by a step -- so with iters_per_epoch = 5, accum = 2 the fifth batch of an epoch is folded into the
+    next epoch's first update (three micro-batches).  The same walk with train_step's rule gives the same windows."""
+    from myriad_amd.myriad import accum_update_due
+    iters, accum, epochs = 5, 2, 3
+    ref_windows, cur = [], []
+    for ep in range(epochs):                      # the reference's loop, literally
+        for i in range(iters):
+            cur.append((ep, i))                   # loss.backward(): accumulates into .grad
+            if (i + 1) % accum == 0:
+                ref_windows.append(cur)           # optimizer.step(); optimizer.zero_grad()
+                cur = []
+    got, cur, count = [], [], 0
+    for ep in range(epochs):
+        for i in range(iters):
+            cur.append((ep, i))
+            count += 1
+            if accum_update_due(count, accum, accum_index=i):
+                got.append(cur)
+                cur, count = [], 0
+    assert got == ref_windows and [len(w) for w in got] == [2, 2, 3, 2, 3, 2]
+    # without the epoch index: every accum-th call
+    assert [accum_update_due(c, 2) for c in (1, 2, 3)] == [False, True, True]

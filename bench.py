@@ -262,6 +262,8 @@ def main():
     ap.add_argument("--no-prefetch-vit", action="store_true",
                     help="run the frozen ViT forward inline at the start of its own step instead of one step ahead on a side stream")
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 line (BASELINE configs[1]) reported as config1_b1")
+    ap.add_argument("--no-minigpt4", action="store_true",
+                    help="skip the MiniGPT-4 arch line (SURVEY 8d's second reported workload, S = 81) reported as config_minigpt4_b8")
     ap.add_argument("--host-inputs", action="store_true",
                     help="inputs start in (pinned) host memory and every step uploads a fresh batch: the PCIe-inclusive rate "
                          "(DESIGN.md; never the headline `value`, whose inputs are resident in HBM)")
@@ -452,6 +454,43 @@ def main():
                                                           "(weight-streaming regime)")
         except Exception as e:                                    # noqa: BLE001
             extra["config1_b1"] = dict(value=None, error=repr(e))
+    if not a.no_minigpt4 and rank == 0 and world == 1 and a.arch == "myriad":
+        # SURVEY 8(d) / BASELINE.md section 2 name two reported workloads: Myriad stage 1 (the headline above, the worst case)
+        # and the MiniGPT-4 baseline arch (mini_gpt4.py:153-257, minigpt4_stage2_finetune.yaml: no expert tokens, S = 81, only
+        # llama_proj trainable) at the same per-GPU batch -- same protocol as the headline (look-ahead ViT, AdamW inside), 3 + 5 steps.
+        try:
+            model = None                                          # release the headline model (the closures above see None)
+            torch.cuda.empty_cache()
+            w2 = SyntheticWeights(cfg, dev, seed=0, arch="mini_gpt4")
+            m2 = MiniGPT4HIP(w2, dict(fixed_stage=0, fixed_taskstage=0, vit_heads=cfg["vit_heads"], qf_heads=cfg["qf_heads"],
+                                      llm_heads=cfg["llm_heads"], use_lora=False), device=dev)
+            s2 = make_samples(a.batch, cfg["vocab"], 43, dev)
+            if prefetch:
+                m2.prepare_vit_graph(s2)
+
+            def step2(i):
+                return m2.train_step(s2, sched.step(0, i), 0.05, next_samples=s2 if prefetch else None)
+            for i in range(3):
+                step2(i)
+            m2.finish_update()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(5):
+                l2 = step2(3 + i)
+            m2.finish_update()
+            torch.cuda.synchronize()
+            d2 = (time.perf_counter() - t0) / 5
+            fl2 = flops_per_sample("mini_gpt4", 0, cfg)
+            extra["config_minigpt4_b8"] = dict(
+                value=round(a.batch / d2, 2), unit="images/s", ms_per_step=round(1e3 * d2, 2), steps=5, warmup=3,
+                per_gpu_batch=a.batch, seq_len=fl2["S"], algorithmic_tflop_per_sample=round(fl2["total"] / 1e12, 3),
+                step_frac_of_peak=round(a.batch * fl2["total"] / d2 / 1e12 / PEAK_BF16_TFLOPS, 4), loss=round(float(l2), 4),
+                trainable_params=m2.store.n_params(),
+                workload="MiniGPT-4 arch (SURVEY 8d: the config-2 baseline arch): EVA-ViT-g + Q-Former (32 queries) + llama_proj "
+                         "(trainable) + Vicuna-7B, no expert tokens, no LoRA; fwd+bwd+AdamW")
+            del m2, w2
+        except Exception as e:                                    # noqa: BLE001
+            extra["config_minigpt4_b8"] = dict(value=None, error=repr(e))
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         try:

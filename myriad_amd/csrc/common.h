@@ -184,20 +184,26 @@ __device__ __forceinline__ float block_max(float v, float* red) {
 // rounding of every tensor these results are stored in, and inside the fp32 parity bounds (1e-4) of the kernel tests.  Round 4:
 // the library erff() is ~40 VALU instructions with branches; in the fc1 GEMM's epilogue (one workgroup per CU, 128 outputs per
 // thread, nothing overlapping the store tail) it cost 13 us of a 52 us launch (ViT fc1, 39 launches per step).
-__device__ __forceinline__ float mh_erf_abs(float ax, float gauss /* exp(-ax * ax) */) {
+// The approximation is used in its erfc form, erfc(|u|) = poly(t) * exp(-u^2): the cdf of a negative argument is 0.5 * erfc(|u|)
+// directly, not 1 - (1 - ...), so the negative tail keeps its sign and magnitude (relative error <= 1 % down to x = -8, where
+// gelu is 1e-15; the 1 - erf form lost everything below x = -5: ADVICE r4).
+__device__ __forceinline__ float mh_erfc_abs(float ax, float gauss /* exp(-ax * ax) */) {
   const float t = __builtin_amdgcn_rcpf(1.f + 0.3275911f * ax);
   const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
-  return 1.f - poly * gauss;
+  return poly * gauss;
+}
+__device__ __forceinline__ float mh_norm_cdf(float u /* x / sqrt(2) */, float gauss) {
+  const float half = 0.5f * mh_erfc_abs(fabsf(u), gauss);
+  return u < 0.f ? half : 1.f - half;
 }
 __device__ __forceinline__ float gelu_erf(float x) {
-  const float u = x * 0.70710678118654752440f, au = fabsf(u);
-  const float e = mh_erf_abs(au, __expf(-au * au));
-  return 0.5f * x * (1.f + copysignf(e, u));
+  const float u = x * 0.70710678118654752440f;
+  return x * mh_norm_cdf(u, __expf(-u * u));
 }
 __device__ __forceinline__ float gelu_erf_grad(float x) {
-  const float u = x * 0.70710678118654752440f, au = fabsf(u);
-  const float g = __expf(-au * au);                     // = exp(-x^2 / 2): the Gaussian of the pdf and of the erf formula
-  const float cdf = 0.5f * (1.f + copysignf(mh_erf_abs(au, g), u));
+  const float u = x * 0.70710678118654752440f;
+  const float g = __expf(-u * u);                       // = exp(-x^2 / 2): the Gaussian of the pdf and of the erfc formula
+  const float cdf = mh_norm_cdf(u, g);
   const float pdf = 0.39894228040143267794f * g;
   return cdf + x * pdf;
 }

@@ -255,3 +255,40 @@ def test_vit_prefetch_on_a_side_stream_changes_nothing(model):
     finally:
         st.flat_p.copy_(keep[0]); st.flat_m.copy_(keep[1]); st.flat_v.copy_(keep[2]); st.step = keep[3]; st.steps_dev.copy_(keep[4])
         model._vit_prefetched, model._vit_rest = None, None
+
+
+def test_minigpt4_arch_b8_is_deterministic_batch_independent_and_trains():
+    """The MiniGPT-4 baseline arch (SURVEY 8d's second reported workload; mini_gpt4.py:153-257, minigpt4_stage2_finetune.yaml:
+    32 queries, no expert tokens, only llama_proj trainable) at full size and the bench batch: B * S = 8 * 81 = 648 rows --
+    2.53 row tiles of 256, other tile counts and K splits than the Myriad stage-1 shape.  Bit-identical run to run; the batch-8
+    loss is the mean of the eight batch-1 losses and of the two batch-4 halves; the batch gradient is the mean of the halves'
+    gradients; one optimisation step moves llama_proj and lowers the loss on the same batch."""
+    from myriad_amd.myriad import MiniGPT4HIP
+    cfg = full_config()
+    m = MiniGPT4HIP(SyntheticWeights(cfg, DEV, seed=0, arch="mini_gpt4"), dict(fixed_stage=0, fixed_taskstage=0, use_lora=False),
+                    device=DEV)
+    m.train()
+    assert m.store.n_params() == 768 * 4096 + 4096                # llama_proj.weight + bias and nothing else
+    s = samples(8, seed=41)
+    l1, g1 = loss_and_grad(m, s)
+    l2, g2 = loss_and_grad(m, s)
+    assert l1 == l2 and torch.equal(g1, g2)
+    assert torch.isfinite(g1).all() and float(g1.abs().max()) > 0
+    with torch.no_grad():
+        full = float(m._forward_impl(s, False))
+        singles = [float(m._forward_impl(pick(s, slice(i, i + 1)), False)) for i in range(8)]
+        halves = [float(m._forward_impl(pick(s, slice(i, i + 4)), False)) for i in (0, 4)]
+    assert abs(full - l1) < 1e-6 * abs(full)
+    assert abs(full - sum(singles) / 8) < 2e-3 * abs(full), (full, singles)
+    assert abs(full - sum(halves) / 2) < 2e-3 * abs(full), (full, halves)
+    _, ga = loss_and_grad(m, pick(s, slice(0, 4)))
+    _, gb = loss_and_grad(m, pick(s, slice(4, 8)))
+    gm = (ga + gb) / 2
+    assert float((g1 - gm).abs().max()) < 1e-1 * float(g1.abs().max())
+    cos = float((g1.double() @ gm.double()) / (g1.double().norm() * gm.double().norm()))
+    assert cos >= 0.995, cos
+    p0 = m.store.flat_p.clone()
+    la = float(m.train_step(s, 1e-3, 0.05))
+    lb = float(m.train_step(s, 1e-3, 0.05))
+    m.finish_update()
+    assert la == l1 and lb < la and not torch.equal(m.store.flat_p, p0)

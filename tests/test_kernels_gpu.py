@@ -758,6 +758,26 @@ def test_rope_fwd_bwd():
     assert relerr(y.float(), x.float()) < 1e-2
 
 
+def test_gelu_keeps_sign_and_magnitude_in_the_negative_tail():
+    """nn.GELU (erf form: eva_vit.py:54-61, Qformer.py FFN) for x in [-8, -3]: the values are 1e-3 .. 1e-15 and an erf
+    approximation with 1.5e-7 ABSOLUTE error used as 1 + erf(u) loses them (wrong magnitude from x = -5 on, possibly a positive
+    sign).  The library evaluates the erfc form: relative error <= 2 % over the whole tail, never positive."""
+    x = torch.arange(-8.0, -2.999, 1.0 / 32)                               # exact in bf16
+    n = x.numel()
+    a = torch.zeros(n, 64)
+    a[:, 0] = x
+    b = torch.zeros(64, 64)
+    b[0, 0] = 1.0
+    y = ops.gemm(bf(a).to(DEV), bf(b).to(DEV), gelu=True, out_dtype=torch.float32)[:, 0].cpu().double()
+    xd = x.double()
+    want = xd * 0.5 * torch.special.erfc(-xd / 2 ** 0.5)
+    assert bool((y <= 0).all()) and bool((y < 0)[x > -7.5].all())
+    rel = ((y - want).abs() / want.abs())
+    assert float(rel.max()) < 2e-2, float(rel.max())
+    g = ops.gelu_fwd(bf(x.view(1, -1)).to(DEV)).float().cpu().double().view(-1)   # the elementwise form: the same function
+    assert float(((g - want).abs() / want.abs()).max()) < 1e-2 + 2 ** -8
+
+
 def test_silu_mul_and_gelu():
     M, I = 50, 11008
     gu = bf(rnd(M, 2 * I, seed=61)).to(DEV)

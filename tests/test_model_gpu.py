@@ -160,10 +160,21 @@ def test_llama_tiny_ragged_loss_grad_and_greedy_ids():
     e2 = emb.clone().requires_grad_(True)
     R.llama_causal_lm(sd, e2, g["mask"], g["labels"], heads)[0].backward()
     demb = lm.backward()
-    # tiny width (64) + std-0.2 weights amplify bf16 rounding: measured 7.5e-2 of max-abs on the worst element and 4.1e-2 in the
-    # Frobenius norm (deterministic); bounds 9e-2 / 5e-2.  The full-width model is held to 5e-2 of max-abs (below).
+    # Why this bound is 9e-2 and not the 5e-2 the full-width model is held to (below): at width 64 with std-0.2 weights every
+    # layer multiplies the bf16 rounding error of the gradient by ~2.5 (measured, tools/tiny_llama_depth_error.py: the same
+    # weights truncated to ONE layer give 2.9e-2 of max-abs / 1.7e-2 Frobenius, the two layers of this fixture 7.5e-2 / 4.1e-2;
+    # deterministic).  So the one-layer model is asserted at 4e-2 -- inside the 5e-2 class -- and the two-layer one at 9e-2 =
+    # one more factor of 2.5 on 2.9e-2 plus margin; the Frobenius error stays under 5e-2 at both depths.
     assert relerr(demb, e2.grad) < 9e-2
     assert ((demb.cpu() - e2.grad).norm() / e2.grad.norm()).item() < 5e-2
+    sd1 = {n: t for n, t in sd.items() if ".layers." not in n or int(n.split(".layers.")[1].split(".")[0]) < 1}
+    lm1 = LlamaHIP(sd1, heads, DEV)
+    e1 = emb.clone().requires_grad_(True)
+    R.llama_causal_lm(sd1, e1, g["mask"], g["labels"], heads)[0].backward()
+    lm1.forward_loss(emb.to(DEV), g["mask"], g["labels"])
+    d1 = lm1.backward()
+    assert relerr(d1, e1.grad) < 4e-2
+    assert ((d1.cpu() - e1.grad).norm() / e1.grad.norm()).item() < 2.5e-2
     # greedy decode with KV cache: ids equal to the oracle's wherever its margin is healthy
     with torch.no_grad():
         ids_ref, margins = R.greedy_generate(sd, emb[:2, :7], heads, max_new_tokens=12, stop_ids=((7,),),
@@ -228,7 +239,8 @@ def test_composite_step_vs_golden(composite, arch, stage):
         return t if t.dim() != 2 or "meta_net" not in name else None
 
     if stage in (1, 2):
-        w15 = grads["VEInstructor.meta_net.15.weight"]
+        w15 = grads["VEInstructor.meta_net.15.weight"]                     # [768, (ky, kx, ci)]: element by element on a sub-sample
+        assert relerr(w15.reshape(w15.shape[0], -1)[::8, ::8], g[key + "_instr_dw15_sub"]) < 5e-2
         assert abs(w15.norm().item() - g[key + "_instr_dw15_norm"].item()) < 5e-2 * g[key + "_instr_dw15_norm"].item()
         w0 = grads["VEInstructor.meta_net.0.weight"].reshape(4, 3, 3, 1).permute(0, 3, 1, 2)
         assert stem_grad_close(w0, g[key + "_instr_dw0"])
@@ -238,7 +250,8 @@ def test_composite_step_vs_golden(composite, arch, stage):
         assert grads["VEInstructor.meta_net.15.weight"] is None
         assert float(model.store.g["VEInstructor.meta_net.15.weight"].abs().max()) == 0
     if stage in (0, 1):
-        w15 = grads["VETokenizer.meta_net.15.weight"]
+        w15 = grads["VETokenizer.meta_net.15.weight"]                      # [4096, (ky, kx, ci)] = 105 M weights
+        assert relerr(w15.reshape(w15.shape[0], -1)[::64, ::100], g[key + "_tok_dw15_sub"]) < 5e-2
         assert abs(w15.norm().item() - g[key + "_tok_dw15_norm"].item()) < 5e-2 * g[key + "_tok_dw15_norm"].item()
         w0 = grads["VETokenizer.meta_net.0.weight"].reshape(4, 3, 3, 1).permute(0, 3, 1, 2)
         assert stem_grad_close(w0, g[key + "_tok_dw0"])
@@ -352,9 +365,13 @@ def test_flat_logit_decode_ids_equal_up_to_the_first_two_ulp_near_tie():
     assert checked >= 60 and longest >= 12, (checked, longest)
 
 
-def test_myriad_generate_token_ids_vs_oracle(composite):
-    """`Myriad.generate` (stage-1 layout, no BOS, KV-cache greedy decode, row-0 stop rule) against the oracle:
-    generated ids are equal at every step whose oracle top-1/top-2 logit margin is >= 0.1."""
+def test_myriad_generate_output_schema_and_determinism(composite):
+    """`Myriad.generate` on the flat random-weight composite model: the output dict the evaluation script reads
+    (evaluation_aqa_dataset.py:339-387: token ids, the text field, the anomaly map handed through), its shapes, and the same ids
+    from a second call (KV-cache workspace and captured graph reused).  WHICH ids come out is pinned elsewhere, with no margin
+    gate: every id of the full pipeline on the peaked fixture (test_myriad_generate_every_id_equals_the_reference_pipeline,
+    below) and every id up to the first two-ulp near-tie on flat logits (test_flat_logit_decode_ids_equal_up_to_...).  (Until
+    round 5 this test compared ids with the oracle while its top-2 margin stayed >= 0.1 and passed on one compared step.)"""
     g, sd, batch = composite
     image, maps, before, after, tgt, tmask = batch
     model = MyriadHIP(sd, dict(need_backward=False), device=DEV)
@@ -363,20 +380,20 @@ def test_myriad_generate_token_ids_vs_oracle(composite):
     out = model.generate(smp, max_new_tokens=10, stop_ids=((5,),), min_length=1)
     ids = out["token_ids"]
     assert out["ve_anomaly_maps"].shape == maps.shape
+    assert ids.dim() == 2 and ids.shape[0] == image.shape[0] and 1 <= ids.shape[1] <= 10 and ids.dtype == torch.long
+    assert int(ids.min()) >= 0 and int(ids.max()) < sd["llama_model.lm_head.weight"].shape[0]
+    again = model.generate(smp, max_new_tokens=10, stop_ids=((5,),), min_length=1)["token_ids"]
+    assert torch.equal(ids, again)
+    # the first id of the sequence is the arg-max of the prefill's last logits: compare it with the oracle's when the oracle
+    # itself is decided by more than two bf16 ulps of its logit scale (else either id is a correct bf16 answer)
     with torch.no_grad():
         img = R.encode_img(sd, image, maps, 1, "myriad")
         ew = sd["llama_model.model.embed_tokens.weight"]
         wrapped = torch.cat([ew[before], img, ew[after]], 1)
-        ids_ref, margins = R.greedy_generate(sd, wrapped, 32, max_new_tokens=10, stop_ids=((5,),), return_margins=True)
-    n = min(ids.shape[1], ids_ref.shape[1])
-    assert n >= 1
-    checked = 0
-    for t in range(n):
-        if float(margins[:, t].min()) < 0.1:
-            break
-        assert torch.equal(ids[:, t], ids_ref[:, t]), (t, ids, ids_ref, margins)
-        checked += 1
-    assert checked >= 1, margins
+        ids_ref, margins = R.greedy_generate(sd, wrapped, 32, max_new_tokens=1, stop_ids=((5,),), return_margins=True)
+    for b in range(ids.shape[0]):
+        if float(margins[b, 0]) >= 0.1:
+            assert int(ids[b, 0]) == int(ids_ref[b, 0]), (b, ids, ids_ref, margins)
 
 
 @pytest.mark.parametrize("sampled", [False, True])

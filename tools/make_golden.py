@@ -508,9 +508,13 @@ def case_composite(M):
             res[key + "_dB_sub"] = ad.conv2.weight.grad[::16].clone()
             if stage in (1, 2):
                 res[key + "_instr_dw15_norm"] = ins.meta_net[15].weight.grad.norm()
+                g15 = ins.meta_net[15].weight.grad                                  # [768, 1024, 1, 1] -> rows x (ky, kx, ci)
+                res[key + "_instr_dw15_sub"] = g15.permute(0, 2, 3, 1).reshape(g15.shape[0], -1)[::8, ::8].clone()
                 res[key + "_instr_dw0"] = ins.meta_net[0].weight.grad.clone()
             if stage in (0, 1):
                 res[key + "_tok_dw15_norm"] = tok.meta_net[15].weight.grad.norm()
+                g15 = tok.meta_net[15].weight.grad                                  # [4096, 1024, 5, 5] -> rows x (ky, kx, ci)
+                res[key + "_tok_dw15_sub"] = g15.permute(0, 2, 3, 1).reshape(g15.shape[0], -1)[::64, ::100].clone()
                 res[key + "_tok_dw0"] = tok.meta_net[0].weight.grad.clone()
                 res[key + "_tok_dbase_sub"] = tok.base_prompts.grad[:, ::64].clone()
     save("composite_fullwidth", **res)

@@ -304,6 +304,7 @@ def main():
         ones = torch.ones(1, device=dev)
         torch.distributed.all_reduce(ones)
         rccl_ranks = int(ones.item()) if backend == "nccl" else 0
+    n_trainable = model.store.n_params()
     sched = LinearWarmupCosineLRScheduler(None, max_epoch=10, iters_per_epoch=1600, min_lr=0.0, init_lr=1e-4,
                                           warmup_steps=0, warmup_start_lr=1e-6)   # shipped recipe
     samples = make_samples(a.batch, cfg["vocab"], 42 + rank, dev)
@@ -509,7 +510,7 @@ def main():
                        "per_gpu_batch": a.batch, "global_batch": a.batch * world, "seq_len": fl["S"],
                        "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
                        "dp_exchange": (dp.mode + ("+bf16" if dp.grad_dtype == torch.bfloat16 else "")) if world > 1 else None,
-                       "trainable_params": model.store.n_params(),
+                       "trainable_params": n_trainable,
                        "peft_lora_qv_r8": bool(a.lora) and a.arch == "myriad",
                        "algorithmic_tflop_per_sample": round(fl["total"] / 1e12, 3)},
             "loss": round(float(loss), 4), "model_build_s": round(build_s, 1),

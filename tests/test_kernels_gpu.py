@@ -774,8 +774,9 @@ def test_gelu_keeps_sign_and_magnitude_in_the_negative_tail():
     assert bool((y <= 0).all()) and bool((y < 0)[x > -7.5].all())
     rel = ((y - want).abs() / want.abs())
     assert float(rel.max()) < 2e-2, float(rel.max())
-    g = ops.gelu_fwd(bf(x.view(1, -1)).to(DEV)).float().cpu().double().view(-1)   # the elementwise form: the same function
-    assert float(((g - want).abs() / want.abs()).max()) < 1e-2 + 2 ** -8
+    xp = torch.cat([x, x[-7:]])                                            # 168 values: the elementwise kernel takes multiples of 8
+    g = ops.gelu_fwd(bf(xp.view(1, -1)).to(DEV)).float().cpu().double().view(-1)[:n]   # the elementwise form: the same function,
+    assert float(((g - want).abs() / want.abs()).max()) < 1e-2 + 2 ** -8              # its output rounded to bf16
 
 
 def test_silu_mul_and_gelu():

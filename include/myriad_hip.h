@@ -396,6 +396,8 @@ int mh_target_arch(void); /* 950 */
  *   gemm256_impl (1)    plan kernel 2 = gemm_x8_kernel; 0 = gemm_256_kernel
  *   lora_norm_fused (1) LoRA dx + input-norm backward as one kernel (mh_gemm_lora_rmsnorm_bwd), LoRA down inside the norm
  *                       forward (mh_gemm_residual_rmsnorm_lora / mh_rmsnorm_lora_fwd)
+ *   attn_full (1)       mh_attn_fwd without mask / bias and with Sk <= 288, head dim in (32, 96]: one workgroup stages the whole
+ *                       K and V of a (batch, head) (attn_full.hip) instead of 64x64 tiles; 0 = the tiled kernel
  * mh_set_option returns the previous value (0 / 1) or MH_ERR_ARG (unknown name, value not 0 / 1); mh_get_option the current
  * value or MH_ERR_ARG.  Not thread-safe against concurrent launches. */
 int mh_set_option(const char* name, int value);

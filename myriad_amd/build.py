@@ -14,7 +14,7 @@ LIB = os.path.join(HERE, "libmyriad_hip.so")
 # the read-out without its stores, gives wrong results on purpose); the product and the tests never load it
 LIB_DBG = os.path.join(HERE, "libmyriad_hip_dbg.so")
 DBG_SOURCES = ["gemm", "gemm_256", "gemm_x4", "attn_seq", "lora"]      # the files that hold a hook
-SOURCES = ["gemm", "gemm_256", "gemm_x4", "gemv", "attention", "attn_seq", "norm", "elementwise", "conv", "loss", "lowrank", "lora", "expert", "image", "selfsup", "optim", "prof", "ctx", "version"]
+SOURCES = ["gemm", "gemm_256", "gemm_x4", "gemv", "attention", "attn_seq", "attn_full", "norm", "elementwise", "conv", "loss", "lowrank", "lora", "expert", "image", "selfsup", "optim", "prof", "ctx", "version"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=fast"]
 
 

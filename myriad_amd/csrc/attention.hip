@@ -606,6 +606,10 @@ static int launch_bwd(const AttnParams& p, hipStream_t s) {
   return MH_OK;
 }
 
+int mh_launch_attn_full_fwd(const void* q, const void* k, const void* v, void* o, float* lse, int B, int H, int Sq, int Sk, int D,
+                            long q_bs, int ldq, long k_bs, int ldk, long v_bs, int ldv, long o_bs, int ldo, float scale,
+                            hipStream_t stream);
+
 extern "C" int mh_attn_fwd(const void* q, const void* k, const void* v, void* o, float* lse, const float* bias,
                            const int* kv_len, int B, int H, int Sq, int Sk, int D, long q_bs, int ldq, long k_bs,
                            int ldk, long v_bs, int ldv, long o_bs, int ldo, float scale, int causal,
@@ -625,6 +629,11 @@ extern "C" int mh_attn_fwd(const void* q, const void* k, const void* v, void* o,
     hipLaunchKernelGGL(attn_decode_kernel, dim3(B * H), dim3(DNW * 64), sh, stream, p);
     MH_CHECK_LAUNCH();
     return MH_OK;
+  }
+  // the frozen encoders' unmasked attention with all keys of a (batch, head) in one CU's LDS: attn_full.hip
+  if (!bias && !kv_len && !causal && mh_opt(MH_OPT_ATTN_FULL)) {
+    rc = mh_launch_attn_full_fwd(q, k, v, o, lse, B, H, Sq, Sk, D, q_bs, ldq, k_bs, ldk, v_bs, ldv, o_bs, ldo, scale, stream);
+    if (rc != MH_ERR_UNSUPPORTED) return rc;
   }
   if (D <= 64) return launch_fwd<64>(p, stream);
   if (D <= 96) return launch_fwd<96>(p, stream);

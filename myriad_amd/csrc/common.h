@@ -42,6 +42,7 @@ enum MhOpt {
   MH_OPT_GEMM_ZERO_PAD,     // rows past M / N of the 256x256 tile read as zeros (0: copies of the last row)
   MH_OPT_GEMM256_IMPL,      // 1: hand-scheduled 64-deep loop (gemm_x4.hip), 0: the eight-wave fallback kernel (gemm_256.hip)
   MH_OPT_LORA_NORM_FUSED,   // LoRA dx correction + input-norm backward / LoRA down + norm forward as one kernel each
+  MH_OPT_ATTN_FULL,         // whole-sequence forward attention (attn_full.hip) for unmasked Sk <= 288, head dim <= 96
   MH_OPT_COUNT
 };
 int mh_opt(int id);

@@ -52,7 +52,10 @@ typedef __attribute__((ext_vector_type(4))) int int4v_t;
                  "={a[160:191]}"(c[5]), "={a[192:223]}"(c[6]), "={a[224:255]}"(c[7]), "+{v144}"(ra0), "+{v145}"(ra1),           \
                  "+{v146}"(rb0), "+{v147}"(rb1), "+{s44}"(koff), "+{s45}"(cnt), "+{s46}"(wr)                                    \
                : "{v[128:135]}"(voa), "{v[136:143]}"(vob), "{s[36:39]}"(sa), "{s[40:43]}"(sb)                                   \
-               : "memory", "scc", "m0", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", X4_CLOB8(1), X4_CLOB8(2),         \
+               /* m0 is written inside (24 times) but cannot be named here: it is a RESERVED register to the compiler ('inline asm
+                  clobber list contains reserved registers: m0'), which never keeps a value live in it across a statement and
+                  sets it up again in front of each of its own uses (LDS-DMA, movrel, sendmsg) -- ADVICE r4 */ \
+               : "memory", "scc", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", X4_CLOB8(1), X4_CLOB8(2),         \
                  X4_CLOB8(3), X4_CLOB8(4), X4_CLOB8(5), X4_CLOB8(6), X4_CLOB8(7), X4_CLOB8(8), X4_CLOB8(9), X4_CLOB8(10),       \
                  X4_CLOB8(11), "v120", "v121", "v122", "v123", "v124", "v125", "v126", "v127")
 
@@ -420,7 +423,7 @@ __global__ __launch_bounds__(256) void gemm_x4_kernel(const bf16_t* __restrict__
                : "={a[0:31]}"(c[0]), "={a[32:63]}"(c[1]), "={a[64:95]}"(c[2]), "={a[96:127]}"(c[3]), "+{v104}"(ra0),            \
                  "+{v105}"(ra1), "+{v106}"(rb0), "+{v107}"(rb1), "+{s44}"(koff), "+{s45}"(cnt), "+{s46}"(wr)                    \
                : "{v[96:99]}"(voa), "{v[100:103]}"(vob), "{s[36:39]}"(sa), "{s[40:43]}"(sb)                                     \
-               : "memory", "scc", "m0", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", X4_CLOB8(1), X4_CLOB8(2),         \
+               : "memory", "scc", "v0", "v1", "v2", "v3", "v4", "v5", "v6", "v7", "v8", "v9", X4_CLOB8(1), X4_CLOB8(2),         \
                  X4_CLOB8(3), X4_CLOB8(4), X4_CLOB8(5), X4_CLOB8(6), X4_CLOB8(7), X4_CLOB8(8), "v90", "v91", "v92", "v93",      \
                  "v94", "v95")
 

@@ -477,6 +477,41 @@ def test_attention_fwd_bwd(name, B, H, Sq, Sk, D, causal, use_bias, ragged):
         assert relerr(got.float()[m], want_tok[m]) < 2.5e-2, (name, nm)
 
 
+@pytest.mark.parametrize("name,B,H,Sq,Sk,D", [("vit_g", 8, 16, 257, 257, 88), ("vit_b1", 1, 16, 257, 257, 88), ("qf_self", 8, 12, 81, 81, 64),
+                                              ("qf_cross", 8, 12, 81, 257, 64), ("qf_self32", 2, 12, 32, 32, 64), ("ragged", 3, 5, 100, 288, 72),
+                                              ("one_frag", 2, 4, 7, 19, 40)])
+def test_whole_sequence_encoder_attention_vs_reference_and_the_tiled_kernel(name, B, H, Sq, Sk, D):
+    """csrc/attn_full.hip (one workgroup stages ALL keys and values of an (image, head); the frozen encoders' unmasked attention:
+    eva_vit.py:118-148 at head dim 88 -> 96 padded, Qformer.py:169-275 at 64) against an fp32 torch softmax(q k^T * scale) v and
+    against the 64x64-tile kernel it replaces (option attn_full = 0): outputs within the bf16 class of each other, the
+    log-sum-exp the Q-Former backward reads within 1e-3.  q / k / v are strided views of token-major projection outputs (head h
+    at columns h * D, rows wider than the heads), as the models pass them."""
+    W = H * D
+    qkv = bf(rnd(B, Sq, 3 * W + 16, seed=301)).to(DEV)              # q inside a wider row (ld = 3W + 16)
+    kv = bf(rnd(B, Sk, 2 * W, seed=302)).to(DEV)
+    q, k, v = qkv[:, :, :W], kv[:, :, :W], kv[:, :, W:]
+    scale = D ** -0.5
+    hook = _opt_hook("attn_full")
+    try:
+        hook(1)
+        o1, l1 = ops.attn_fwd(q, k, v, H, D, scale)
+        hook(0)
+        o0, l0 = ops.attn_fwd(q, k, v, H, D, scale)
+    finally:
+        hook(1)
+
+    def heads(t, S):
+        return t.float().view(B, S, H, D).transpose(1, 2)
+
+    ref = attn_ref(heads(q, Sq), heads(k, Sk), heads(v, Sk), scale, False, None, None).transpose(1, 2).reshape(B, Sq, W)
+    assert relerr(o1.float(), ref) < 1.5e-2, name
+    assert relerr(o1.float(), o0.float()) < 1.5e-2 and float((l1 - l0).abs().max()) < 1e-3, name
+    sc = torch.einsum("bhqd,bhkd->bhqk", heads(q, Sq), heads(k, Sk)) * scale
+    assert float((l1 - torch.logsumexp(sc, -1)).abs().max()) < 1e-3
+    if Sk > 64:                                                 # more than one key tile: the two kernels sum in different orders,
+        assert not torch.equal(o1, o0)                          # so bit-equal outputs would mean the switch did not switch
+
+
 def test_attention_online_softmax_spike():
     """Force a large running-max jump between KV tiles (guide rule 26): one key row spikes late."""
     B, H, S, D = 1, 2, 200, 64

@@ -248,6 +248,12 @@ int mh_copy3d_f32(const float* src, long src_bstride, long lds, float* dst, long
                   long rows, int cols, int accumulate, mh_stream_t s);
 int mh_gather_rows_f32_to_bf16(const float* src, long lds, const int* rows, void* dst, long n, int D, mh_stream_t s);
 int mh_gather_rows_f32(const float* src, long lds, const int* rows, float* dst, long n, int D, mh_stream_t s);
+/* The same for rows of any 2- or 4-byte element type (16-byte units: D and lds multiples of 16 / elem_bytes), and its inverse with
+ * zero fill: dst[m, :] = inv[m] >= 0 ? src[inv[m], :] : 0 for every row m < M of dst (one launch instead of a fill + a scatter).
+ * llama.py runs the LAST decoder layer's o_proj / MLP (modeling_llama.py:281-293) on the label-bearing rows only and expands the
+ * row gradients back with these. */
+int mh_gather_rows(const void* src, long lds, const int* rows, void* dst, long n, int D, int elem_bytes, mh_stream_t s);
+int mh_expand_rows(const void* src, const int* inv, void* dst, long ldd, long M, int D, int elem_bytes, mh_stream_t s);
 int mh_copy3d_bf16(const void* src, long src_bstride, long lds, void* dst, long dst_bstride, long ldd, int nb,
                    long rows, int cols, mh_stream_t s);
 /* KV-cache append at a device-resident position + device counter bump: lets one decode step be captured in a

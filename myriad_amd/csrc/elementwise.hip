@@ -452,6 +452,53 @@ extern "C" int mh_gather_rows_f32(const float* src, long lds, const int* rows, f
   return MH_OK;
 }
 
+// ---- row gather of 16-byte units (any element type: bf16 rows of D % 8 == 0, f32 rows of D % 4 == 0) and its inverse with
+// zero fill: dst[m, :] = inv[m] >= 0 ? src[inv[m], :] : 0 for every row m of dst -- one launch instead of a fill + a scatter.
+// Used where only the label-bearing rows of a [B*S, D] tensor are non-zero / needed (llama.py: the last decoder layer's
+// o_proj and MLP, modeling_llama.py:281-293, run on those rows only: every other row's output feeds nothing and its gradient is
+// exactly zero).
+__global__ void gather_rows16_kernel(const uint4* __restrict__ src, long lds16, const int* __restrict__ rows, uint4* __restrict__ dst,
+                                     long n, int d16) {
+  const long total = n * d16;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long i = it / d16;
+    const int c = (int)(it - i * d16);
+    dst[i * d16 + c] = src[(long)rows[i] * lds16 + c];
+  }
+}
+__global__ void expand_rows16_kernel(const uint4* __restrict__ src, const int* __restrict__ inv, uint4* __restrict__ dst, long ldd16,
+                                     long M, int d16) {
+  const long total = M * d16;
+  for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
+    const long m = it / d16;
+    const int c = (int)(it - m * d16);
+    const int i = inv[m];
+    dst[m * ldd16 + c] = i >= 0 ? src[(long)i * d16 + c] : make_uint4(0u, 0u, 0u, 0u);
+  }
+}
+// src [*, lds] rows of D elements of elem_bytes (2 or 4) each -> dst [n, D] dense
+extern "C" int mh_gather_rows(const void* src, long lds, const int* rows, void* dst, long n, int D, int elem_bytes,
+                              hipStream_t stream) {
+  if (n <= 0) return MH_OK;
+  const int per16 = 16 / (elem_bytes > 0 ? elem_bytes : 1);
+  if ((elem_bytes != 2 && elem_bytes != 4) || D % per16 || lds % per16 || (((uintptr_t)src | (uintptr_t)dst) & 15)) return MH_ERR_ARG;
+  hipLaunchKernelGGL(gather_rows16_kernel, dim3(ew_grid(n * (D / per16))), dim3(EW_NT), 0, stream, (const uint4*)src, lds / per16, rows,
+                     (uint4*)dst, n, D / per16);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+// dst [M, ldd] : row m = src row inv[m] (src dense [*, D]) or zeros when inv[m] < 0
+extern "C" int mh_expand_rows(const void* src, const int* inv, void* dst, long ldd, long M, int D, int elem_bytes,
+                              hipStream_t stream) {
+  if (M <= 0) return MH_OK;
+  const int per16 = 16 / (elem_bytes > 0 ? elem_bytes : 1);
+  if ((elem_bytes != 2 && elem_bytes != 4) || D % per16 || ldd % per16 || (((uintptr_t)src | (uintptr_t)dst) & 15)) return MH_ERR_ARG;
+  hipLaunchKernelGGL(expand_rows16_kernel, dim3(ew_grid(M * (D / per16))), dim3(EW_NT), 0, stream, (const uint4*)src, inv, (uint4*)dst,
+                     ldd / per16, M, D / per16);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
 // ---- batched 2-D copy of bf16 (KV-cache append / slicing); cols % 8 == 0 --------------------------
 __global__ void copy3d_bf16_kernel(const bf16_t* __restrict__ src, long sb, long lds, bf16_t* __restrict__ dst,
                                    long db, long ldd, int nb, long rows, int cols8) {

@@ -90,6 +90,7 @@ class LlamaHIP:
         # (55.7 -> 55.1 ms per step: they run beside the Q-Former backward); MYRIAD_LORA_DEFER=0 computes them in place
         self.defer_lora_wgrad = os.environ.get("MYRIAD_LORA_DEFER", "1") != "0"
         self.decode_fused = os.environ.get("MYRIAD_DECODE_FUSED", "1") != "0"
+        self.last_layer_rows = os.environ.get("MYRIAD_LAST_LAYER_ROWS", "1") != "0"
         self._packed = None
         self._decode_ws = {}
 
@@ -142,7 +143,28 @@ class LlamaHIP:
         # whole-sequence attention with the rotary embedding fused (csrc/attn_seq.hip) when the sequence fits a CU's LDS:
         # qkv is then saved PRE-rotary and the backward kernel rotates again / un-rotates dq, dk itself
         fused_attn = ops.attn_rope_supported(S, hd) and os.environ.get("MYRIAD_ATTN_SEQ", "1") != "0"
+        # loss on label-bearing rows only: row (b,s) predicts labels[b,s+1]
+        lab = labels.to("cpu")
+        shift = lab[:, 1:]
+        bi, si = torch.nonzero(shift != -100, as_tuple=True)
+        n_valid = int(bi.numel())
+        if n_valid == 0:
+            raise ValueError("no valid labels")
+        row_idx = (bi * S + si).to(torch.int32)
+        rows = ops.h2d(row_idx, self.dev)
+        tgt = ops.h2d(shift[bi, si], self.dev)
+        # The LAST layer's o_proj, post-attention norm and MLP (modeling_llama.py:281-293) run on those rows only: the other rows
+        # of its output feed nothing (the final norm and lm_head read label rows), and in the backward their gradient is exactly
+        # zero down to that layer's attention, which mixes rows -- so its k / v projections and everything below stay dense.
+        # Identical results, ~1.4 % fewer executed FLOPs at the bench shape; MYRIAD_LAST_LAYER_ROWS=0 keeps every row.
+        last_rows = self.last_layer_rows and len(self.layers) > 0 and n_valid < M
+        inv = None
+        if last_rows:
+            inv_host = torch.full((M,), -1, dtype=torch.int32)
+            inv_host[row_idx.long()] = torch.arange(n_valid, dtype=torch.int32)
+            inv = ops.h2d(inv_host, self.dev)
         xn = ops.rmsnorm_fwd(h, self.layers[0]["ln1"], self.eps, out=norm_target(0)) if self.layers else None
+        hr = None
         for li, L in enumerate(self.layers):
             lsave = None
             if lora is None:
@@ -160,6 +182,15 @@ class LlamaHIP:
                 ops.rope_(qkv, 0, 2 * H, hd, pos, self.cos, self.sin, 1.0)  # q and k heads
                 o, lse = ops.attn_fwd(q3[:, :, :W], q3[:, :, W:2 * W], q3[:, :, 2 * W:], H, hd, scale, causal=True,
                                       kv_len=kv_len)
+            if last_rows and li + 1 == len(self.layers):
+                o_r = ops.gather_rows(o.view(M, W), rows)                   # [R, W] bf16
+                h_r = ops.gather_rows(h, rows)                              # [R, D] f32
+                h2, xn2 = ops.gemm_residual_rmsnorm(o_r, L["wo"], h_r, L["ln2"], self.eps)
+                gu, act = ops.gemm_swiglu_fwd(xn2, L["wgu"])
+                hr = ops.gemm(act, L["wd"], residual=h2, out_dtype=F32)     # the final hidden state of the label rows
+                if save_for_backward:
+                    saved.append((h, qkv, o, lse, h2, gu, lsave))
+                break
             h2, xn2 = ops.gemm_residual_rmsnorm(o.view(M, W), L["wo"], h, L["ln2"], self.eps)
             gu, act = ops.gemm_swiglu_fwd(xn2, L["wgu"])                    # [M, 2I] (interleaved g|u blocks), [M, I]
             if li + 1 < len(self.layers):
@@ -170,23 +201,15 @@ class LlamaHIP:
             if save_for_backward:
                 saved.append((h, qkv, o, lse, h2, gu, lsave))
             h = h3
-        # loss on label-bearing rows only: row (b,s) predicts labels[b,s+1]
-        lab = labels.to("cpu")
-        shift = lab[:, 1:]
-        bi, si = torch.nonzero(shift != -100, as_tuple=True)
-        rows = ops.h2d((bi * S + si).to(torch.int32), self.dev)
-        tgt = ops.h2d(shift[bi, si], self.dev)
-        n_valid = int(rows.numel())
-        if n_valid == 0:
-            raise ValueError("no valid labels")
-        hr = ops.gather_rows_f32(h, rows)
+        if hr is None:
+            hr = ops.gather_rows_f32(h, rows)
         hn = ops.rmsnorm_fwd(hr, self.norm, self.eps)
         logits = ops.gemm(hn, self.lm_head, out_dtype=F32)                  # [R, V] f32
         row_loss, dlogits = ops.clamp_ce(logits, tgt, 1.0 / n_valid, want_grad=save_for_backward, ldd=self.Vpad)
         loss = ops.sum_f32(row_loss, 1.0 / n_valid)
         if save_for_backward:
             self._saved = dict(layers=saved, rows=rows, hr=hr, dlogits=dlogits, B=B, S=S, kv_len=kv_len, pos=pos,
-                               scale=scale, fused_attn=fused_attn)
+                               scale=scale, fused_attn=fused_attn, inv=inv)
         return loss.view(())
 
     # ------------------------------------------------------------------ dgrad-only backward
@@ -204,19 +227,38 @@ class LlamaHIP:
             raise NotImplementedError("loss scaling is unnecessary in bf16; pass 1.0")
         dhn = ops.gemm(dlog, self.lm_headT, out_dtype=F32)                  # [R, D]
         dhr, _ = ops.rmsnorm_bwd(dhn, sv["hr"], self.norm, self.eps)
-        dh = torch.zeros((M, D), dtype=F32, device=self.dev)
-        ops.scatter_rows(dhr, sv["rows"], dh)
-        dh_b = ops.to_bf16(dh)
+        inv = sv.get("inv")
+        if inv is None:
+            dh = torch.zeros((M, D), dtype=F32, device=self.dev)
+            ops.scatter_rows(dhr, sv["rows"], dh)
+            dh_b = ops.to_bf16(dh)
         n_layers = len(self.layers)
         for ri, (L, (h_in, qkv, o, lse, h2, gu, lsave)) in enumerate(zip(reversed(self.layers), reversed(sv["layers"]))):
             li = n_layers - 1 - ri
-            dgu = ops.gemm_swiglu_bwd(dh_b, L["wdT"], gu)                   # down dgrad + gate backward: [M, 2I]
-            # gate|up dgrad [M, D] and the post-attention norm's backward in one call (split-K slabs summed in the norm kernel)
-            dh2, dh2_b = ops.gemm_rmsnorm_bwd(dgu, L["wguT"], h2, L["ln2"], self.eps, dres=dh)
+            rows_mode = inv is not None and ri == 0      # the last layer ran its o_proj / MLP on the label rows only (forward_loss)
+            if rows_mode:
+                dgu = ops.gemm_swiglu_bwd(ops.to_bf16(dhr), L["wdT"], gu)   # [R, 2I]: every other row's gradient is exactly zero
+                dh2_r, dh2_rb = ops.gemm_rmsnorm_bwd(dgu, L["wguT"], h2, L["ln2"], self.eps, dres=dhr)
+                do_r = ops.gemm(dh2_rb, L["woT"])                           # [R, W] bf16
+                dh2 = ops.expand_rows(dh2_r, inv, M)                        # back to all rows (zeros elsewhere): the residual path
+                do = ops.expand_rows(do_r, inv, M)                          # ... and the attention's dO
+            else:
+                dgu = ops.gemm_swiglu_bwd(dh_b, L["wdT"], gu)               # down dgrad + gate backward: [M, 2I]
+                # gate|up dgrad [M, D] and the post-attention norm's backward in one call (split-K slabs summed in the norm kernel)
+                dh2, dh2_b = ops.gemm_rmsnorm_bwd(dgu, L["wguT"], h2, L["ln2"], self.eps, dres=dh)
             q3 = qkv.view(B, S, 3 * W)
             dqkv = torch.empty_like(qkv)
             d3 = dqkv.view(B, S, 3 * W)
-            if sv["fused_attn"]:
+            if rows_mode:
+                if sv["fused_attn"]:
+                    ops.attn_rope_bwd(q3, o, do.view(B, S, W), lse, H, hd, sv["scale"], sv["pos"], self.cos, self.sin,
+                                      kv_len=sv["kv_len"], dqkv=d3)
+                else:
+                    ops.attn_bwd(q3[:, :, :W], q3[:, :, W:2 * W], q3[:, :, 2 * W:], o, do.view(B, S, W), lse, H, hd,
+                                 sv["scale"], causal=True, kv_len=sv["kv_len"], dq=d3[:, :, :W], dk=d3[:, :, W:2 * W],
+                                 dv=d3[:, :, 2 * W:])
+                    ops.rope_(dqkv, 0, 2 * H, hd, sv["pos"], self.cos, self.sin, -1.0)
+            elif sv["fused_attn"]:
                 # o_proj dgrad + attention backward: the split-K slabs of dO are summed inside the attention kernel
                 ops.gemm_attn_rope_bwd(dh2_b, L["woT"], q3, o, lse, H, hd, sv["scale"], sv["pos"], self.cos, self.sin,
                                        kv_len=sv["kv_len"], dqkv=d3)

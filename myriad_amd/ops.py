@@ -626,6 +626,22 @@ def gather_rows_bf16(src: torch.Tensor, rows: torch.Tensor):
     return out
 
 
+def gather_rows(src: torch.Tensor, rows: torch.Tensor):
+    """src [*, D] (bf16 or f32, row stride free) -> [n, D] dense, same dtype: rows `rows` (int32, device)."""
+    n, D = rows.numel(), src.shape[1]
+    out = torch.empty((n, D), dtype=src.dtype, device=src.device)
+    _lib.check(_L().mh_gather_rows(_p(src), src.stride(0), _p(rows), _p(out), n, D, src.element_size(), _s()), "mh_gather_rows")
+    return out
+
+
+def expand_rows(src: torch.Tensor, inv: torch.Tensor, M: int):
+    """[n, D] dense -> [M, D] with row m = src[inv[m]] or zeros where inv[m] < 0 (inv int32 [M], device)."""
+    D = src.shape[1]
+    out = torch.empty((M, D), dtype=src.dtype, device=src.device)
+    _lib.check(_L().mh_expand_rows(_p(src), _p(inv), _p(out), D, M, D, src.element_size(), _s()), "mh_expand_rows")
+    return out
+
+
 def gather_rows_f32(src: torch.Tensor, rows: torch.Tensor):
     n, D = rows.numel(), src.shape[1]
     out = torch.empty((n, D), dtype=F32, device=src.device)

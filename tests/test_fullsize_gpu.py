@@ -292,3 +292,25 @@ def test_minigpt4_arch_b8_is_deterministic_batch_independent_and_trains():
     lb = float(m.train_step(s, 1e-3, 0.05))
     m.finish_update()
     assert la == l1 and lb < la and not torch.equal(m.store.flat_p, p0)
+
+
+def test_last_layer_on_label_rows_only_changes_nothing_but_rounding(model):
+    """forward_loss runs the LAST decoder layer's o_proj / post-attention norm / MLP on the label-bearing rows only (the other rows
+    of its output feed nothing; in the backward their gradient is exactly zero down to that layer's attention).  Against the same
+    model with every row kept (llama.last_layer_rows = False; other row counts pick other GEMM kernels and K splits, so the bits
+    differ as between any two batch compositions): loss within 1e-3 relative, the 115 M gradients within 5e-2 of max-abs and
+    cosine >= 0.999 -- and the d(inputs_embeds) the adapters receive likewise."""
+    s = samples(8, seed=24)
+    llm = model.llama
+    try:
+        llm.last_layer_rows = True
+        la, ga = loss_and_grad(model, s)
+        llm.last_layer_rows = False
+        lb, gb = loss_and_grad(model, s)
+    finally:
+        llm.last_layer_rows = True
+    assert la != lb or not torch.equal(ga, gb)                   # the switch reaches the kernels
+    assert abs(la - lb) < 1e-3 * abs(lb), (la, lb)
+    assert float((ga - gb).abs().max()) < 5e-2 * float(gb.abs().max())
+    cos = float((ga.double() @ gb.double()) / (ga.double().norm() * gb.double().norm()))
+    assert cos >= 0.999, cos

@@ -12,6 +12,9 @@ dev = torch.device("cuda:0")
 ops.ensure_workspace(dev)
 SHAPES = [(148, 12288, 4160), (148, 4096, 4096), (148, 22016, 4096), (148, 4096, 11008), (148, 4096, 22016), (148, 4160, 12288),
           (148, 11008, 4096), (257, 6144, 1408), (257, 1408, 6144), (257, 4224, 1408), (257, 1408, 1408)]
+if len(sys.argv) > 1:      # `gemm_m148_sweep.py 128`: the LLaMA layer's products at another row count (round 5: the last layer's label rows)
+    m = int(sys.argv[1])
+    SHAPES = [(m, 4096, 4096), (m, 22016, 4096), (m, 4096, 11008), (m, 11008, 4096), (m, 4096, 22016)]
 
 
 def timeit(fn, bs):

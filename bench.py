@@ -516,9 +516,11 @@ def main():
             "loss": round(float(loss), 4), "model_build_s": round(build_s, 1),
             # whole-step algorithmic FLOPs (SURVEY 8d F_step x per-GPU batch) / measured step time / dense bf16 peak, per GPU
             "step_frac_of_peak": round(step_tflops / PEAK_BF16_TFLOPS, 4),
-            # F_step is the REFERENCE's arithmetic (full S x S attention, lm_head over all S rows); the HIP path
-            # runs causal attention and the lm_head on the 16 label rows per sample only (identical results), ~2 % fewer FLOPs
-            "flop_accounting": "reference-algorithmic (SURVEY 8d); executed FLOPs are ~2 % lower (causal attention, lm_head on label rows)",
+            # F_step is the REFERENCE's arithmetic (full S x S attention, lm_head and the last layer over all S
+            # rows); the HIP path runs causal attention, the lm_head on the 16 label rows per sample and -- round 5 -- the LAST
+            # decoder layer's o_proj / MLP on those rows only (identical results: the other rows feed nothing and carry exactly-zero
+            # gradients), ~4 % fewer executed FLOPs
+            "flop_accounting": "reference-algorithmic (SURVEY 8d); executed FLOPs are ~4 % lower (causal attention; lm_head and the last layer's o_proj / MLP on label rows only)",
             "dp_collective": ("mh_ctx" if getattr(dp, "ctx", None) is not None else "torch.distributed") if world > 1 else None,
         }
         if roof is not None:

@@ -27,6 +27,7 @@
 #define MH_GEMM_REGSTAGE 4
 #define MH_GEMM_GELU_PRE 64    // internal (mh_gemm_gelu_fwd): aux <- bf16 pre-activation, C <- gelu of it
 #define MH_GEMM_GELU_BWD 128   // internal (mh_gemm_gelu_bwd): C <- bf16(product) * gelu'(aux)
+#define MH_GEMM_PACKED_B (1 << 20)   // internal: B is tile-packed, [N / TBN][K / 64][TBN rows][64] (one 16-KiB block per k-tile of a column tile)
 #define MH_GEMM_VARIANT_SHIFT 8  // bits 8..11: 0 = auto, 1 = 2-stage/128, 2 = 4-stage/128, 3 = 3-stage/64, 4 = 2-stage/64
 
 typedef __attribute__((address_space(3))) void lds_void_t;
@@ -106,13 +107,15 @@ __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void gemm_nt_kernel(const b
     ra = ra < M ? ra : M - 1;
     gA[i] = A + (size_t)ra * lda + lc * 8;
   }
+  const bool packed_b = flags & MH_GEMM_PACKED_B;
+  const int kmul_b = packed_b ? TBN : 1;         // element step of B per k element: a packed k-tile is TBN * 64 elements away
 #pragma unroll
   for (int i = 0; i < NB; ++i) {
     const int c = i * NT + tid;
     const int row = c / CPR, lc = swz_src_chunk<TBK>(row, c % CPR);
     int rb = n0 + row;
     rb = rb < N ? rb : N - 1;
-    gB[i] = B + (size_t)rb * ldb + lc * 8;
+    gB[i] = packed_b ? B + (size_t)tn * K * TBN + (size_t)row * BK + lc * 8 : B + (size_t)rb * ldb + lc * 8;
   }
 
   float4_t acc[MI][NJ];
@@ -136,7 +139,7 @@ __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void gemm_nt_kernel(const b
       __builtin_amdgcn_global_load_lds((gbl_void_t*)(gA[i] + k0), (lds_void_t*)(sA + (i * NT + wave * 64) * 16), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      __builtin_amdgcn_global_load_lds((gbl_void_t*)(gB[i] + k0), (lds_void_t*)(sB + (i * NT + wave * 64) * 16), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((gbl_void_t*)(gB[i] + (size_t)k0 * kmul_b), (lds_void_t*)(sB + (i * NT + wave * 64) * 16), 16, 0, 0);
   };
   auto compute = [&](int stage) {
     const char* sA = smem + stage * STAGE;
@@ -466,7 +469,7 @@ static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t str
   if (slab_bf16) *slab_bf16 = sbf;
   GemmArgs g = g0;
   g.C = (void*)ws; g.ldc = g0.N; g.bias = nullptr; g.residual = nullptr; g.ldr = 0;
-  g.flags = sbf ? 0 : MH_GEMM_OUT_F32; g.alpha = 1.0f; g.splits = splits; g.tps = tps; g.split_stride = (long)g0.M * g0.N;
+  g.flags = (sbf ? 0 : MH_GEMM_OUT_F32) | (g0.flags & MH_GEMM_PACKED_B); g.alpha = 1.0f; g.splits = splits; g.tps = tps; g.split_stride = (long)g0.M * g0.N;
   int rc;
   const int var = (g0.flags >> MH_GEMM_VARIANT_SHIFT) & 15;
   if (big)
@@ -592,7 +595,9 @@ static inline int plan_variant(int kernel) {
 //             CU's L2 rate (~0.5 us per 64-deep step), so twice the workgroups is twice the CUs pulling: 14 -> 10 us at
 //             K = 768, 27 -> 19 us at K = 2304 (tools/gemm_small_sweep.py); same k order per accumulator, same bits
 static int g_force_kernel = -1, g_force_splits = 0;
+static int g_dbg_flags = 0;
 #ifdef MH_DEBUG_HOOKS
+extern "C" void mhdbg_or_gemm_flags(int f) { g_dbg_flags = f; }   // timing experiments: internal flag bits OR-ed into every auto-planned launch
 extern "C" void mhdbg_set_force_plan(int kernel, int splits) { g_force_kernel = kernel; g_force_splits = splits; }   // sweep tools (libmyriad_hip_dbg.so only)
 #endif
 
@@ -688,7 +693,7 @@ extern "C" int mh_gemm_bf16_nt(const void* A, int lda, const void* B, int ldb, v
     if (kernel == 0)
       return mh_launch_gemv(A, lda, B, ldb, C, ldc, M, N, K, bias, residual, ldr, (flags & MH_GEMM_OUT_F32) ? 1 : 0,
                             alpha, stream);
-    g.flags |= plan_variant(kernel) << MH_GEMM_VARIANT_SHIFT;
+    g.flags |= (plan_variant(kernel) << MH_GEMM_VARIANT_SHIFT) | g_dbg_flags;
     // the split-K reduce reads `residual` and writes C element-wise, so C may alias residual (in-place accumulate)
     return splits > 1 ? run_splitk(g, splits, ws_for(stream), stream) : dispatch(g, stream);
   }

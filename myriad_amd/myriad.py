@@ -426,6 +426,18 @@ class MyriadHIP(nn.Module):
         use_ins = self.arch == "myriad" and stage in (1, 2)
         use_tok = self.arch == "myriad" and stage in (0, 1)
         nq = self.nq0 + (49 if use_ins else 0)
+        # The map tokenizer's conv stack (networks.py:159-197) reads only the anomaly map and its tokens are first needed by the
+        # prompt assembly, behind the whole Q-Former forward: it runs on the leaf side stream (its own split-K scratch; the stream
+        # its backward runs on) beside that chain instead of ~0.3 ms behind it.  Joined before the tokens are used.
+        tok_out, tok_ev = None, None
+        if use_tok and self._leaf_aside and self._dev.type == "cuda":
+            aux, main = self._side_stream("leaf"), torch.cuda.current_stream()
+            aux.wait_stream(main)                                     # parameters (AdamW) and the map are ordered on the main stream
+            maps.record_stream(aux)
+            with torch.cuda.stream(aux):
+                tok_out = self.ve_tok.forward(maps, save)
+                tok_ev = torch.cuda.Event()
+                tok_ev.record()
         q = torch.empty((B, nq, self.Dq), dtype=F32, device=self._dev)
         ops.copy3d(self.query_tokens_f32.expand(B, -1, -1), q[:, :self.nq0])
         if use_ins:
@@ -440,7 +452,12 @@ class MyriadHIP(nn.Module):
         parts = [img.view(B, nq, self.Dl)]
         if use_tok:
             parts.append(self.store.p["VETokenizer.base_prompts"].view(1, 9, self.Dl).expand(B, -1, -1))
-            parts.append(self.ve_tok.forward(maps, save))
+            if tok_ev is not None:
+                torch.cuda.current_stream().wait_event(tok_ev)
+                tok_out.record_stream(torch.cuda.current_stream())    # allocated on the side stream, read here
+                parts.append(tok_out)
+            else:
+                parts.append(self.ve_tok.forward(maps, save))
         if save:
             self._ctx = dict(B=B, N=N, y=y, nq=nq, use_ins=use_ins, use_tok=use_tok, qo_b=qo_b)
         return parts

@@ -623,17 +623,31 @@ class MyriadHIP(nn.Module):
         else:
             leaf_ev, leaf_keep = None, None
         dq, denc = self.qformer.backward(dqo)
+        ins_ev, ins_keep = None, None
         if c["use_ins"]:
             dins = torch.empty((B, 49, self.Dq), dtype=F32, device=self._dev)
             ops.copy3d(dq[:, self.nq0:], dins)
-            self.ve_ins.backward(dins)
+            if self._leaf_aside and self._dev.type == "cuda" and os.environ.get("MYRIAD_INS_ASIDE", "1") != "0":
+                # the instructor's conv stack is a leaf too (its input is the anomaly map): its backward runs on the leaf stream
+                # beside ln_vision's and the adaptor's backward
+                aux, main = self._side_stream("leaf"), torch.cuda.current_stream()
+                aux.wait_stream(main)
+                ins_keep = (dins, self.ve_ins._saved)     # main-stream allocations the side stream reads: alive until the join
+                with torch.cuda.stream(aux):
+                    self.ve_ins.backward(dins)
+                    ins_ev = torch.cuda.Event()
+                    ins_ev.record()
+            else:
+                self.ve_ins.backward(dins)
         dy, _ = ops.layernorm_bwd(denc.view(B * c["N"], self.Dv), c["y"], self.ln_w, 1e-5)
         self.adaptor.backward(dy)
         if self.llama.lora is not None:
             self.llama.lora.join_wgrads()                 # the side-stream LoRA weight gradients land before anyone reads flat_g
         if leaf_ev is not None:
             torch.cuda.current_stream().wait_event(leaf_ev)
-        del leaf_keep                                     # freed only now: later main-stream work is ordered behind the event
+        if ins_ev is not None:
+            torch.cuda.current_stream().wait_event(ins_ev)
+        del leaf_keep, ins_keep                           # freed only now: later main-stream work is ordered behind the events
         self._finish_backward()
 
     def _finish_backward(self):

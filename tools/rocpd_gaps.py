@@ -13,13 +13,16 @@ cols = [r[1] for r in db.execute("pragma table_info(kernels)")]
 qcol = next(c for c in ("stream_id", "queue_id", "stream", "queue") if c in cols)
 ce = [r[0] for r in db.execute("select start from kernels where name like '%clamp_ce%' order by start")]
 marks = [r[0] for r in db.execute("select start from kernels where name like '%mh_prof_marker_kernel%' order by start")]
-best, bt = None, -1
+# the step window: among the un-instrumented clamp_ce-to-clamp_ce windows whose kernel time is within 15 % of the heaviest (the
+# batch-8 steps), the one with the SHORTEST wall -- a window that straddles the end of the timed region carries host pauses
+cands = []
 for i in range(len(ce) - 1):
     if len(marks) >= 2 and not (ce[i + 1] < marks[0] or ce[i] > marks[1]):
         continue
     s = db.execute("select sum(end-start) from kernels where start>=? and start<?", (ce[i], ce[i + 1])).fetchone()[0] or 0
-    if s > bt:
-        best, bt = (ce[i], ce[i + 1]), s
+    cands.append((s, ce[i + 1] - ce[i], (ce[i], ce[i + 1])))
+top = max(c[0] for c in cands)
+best = min((c for c in cands if c[0] >= 0.85 * top), key=lambda c: c[1])[2]
 t0, t1 = best
 rows = db.execute(f"select name, start, end, {qcol} from kernels where start>=? and start<? order by start", (t0, t1)).fetchall()
 short = lambda n: re.sub(r"\(.*", "", re.sub(r"^void ", "", n))[:48]

@@ -16,7 +16,9 @@ def ktime(w):
     return db.execute("select sum(end-start) from kernels where start>=? and start<?", w).fetchone()[0] or 0
 
 
-w = max(wins, key=ktime)
+_kt = {x: ktime(x) for x in wins}
+_top = max(_kt.values())
+w = min((x for x in wins if _kt[x] >= 0.85 * _top), key=lambda x: x[1] - x[0])     # a batch-8 step without host pauses in it
 out = [f"window {(w[1] - w[0]) / 1e6:.2f} ms"]
 for pat in sys.argv[2:]:
     c, s, a = db.execute("select count(*), sum(end-start), avg(end-start) from kernels where start>=? and start<? and name like ?",

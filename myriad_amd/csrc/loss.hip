@@ -223,10 +223,85 @@ extern "C" int mh_decode_record(const long* nxt, const float* margin, const floa
   return MH_OK;
 }
 
+// arg-max, top-1 / top-2 margin and p_max of a row in ONE launch with the row in registers (1024 threads, V <= 32768, 16-byte
+// aligned rows): the decode step's lm-head tail was two single-workgroup scans of 128 KB with 4-byte loads (42 + 20 us per token).
+// Same rules as argmax_kernel (first index on ties, the banned id counts as -inf, a duplicate of the maximum gives margin 0) and
+// pmax_kernel (banned id excluded); the exponentials are summed in another order (both deterministic).
+struct AmTop { float best; int idx; float second; };
+__device__ __forceinline__ AmTop am_combine(const AmTop& a, const AmTop& b) {
+  const bool take_b = (b.best > a.best) || (b.best == a.best && b.idx < a.idx);
+  AmTop o;
+  o.best = take_b ? b.best : a.best;
+  o.idx = take_b ? b.idx : a.idx;
+  o.second = fmaxf(fmaxf(a.second, b.second), take_b ? a.best : b.best);
+  return o;
+}
+__global__ __launch_bounds__(LNT_W) void argmax_pmax_wide_kernel(const float* __restrict__ logits, long ldl, long* __restrict__ out,
+                                                                 float* __restrict__ margin, float* __restrict__ pmax, int V, int ban_id,
+                                                                 float inv_temp) {
+  __shared__ float sb[LNT_W / 64], s2[LNT_W / 64], red[LNT_W / 64];
+  __shared__ int si[LNT_W / 64];
+  const long row = blockIdx.x;
+  const float* x = logits + row * ldl;
+  const float ninf = -__builtin_inff();
+  float4_t xv[8];
+  const int t4 = (int)threadIdx.x * 4;
+  AmTop tp = {ninf, t4 < V ? t4 : 0, ninf};          // the index stays in range even if every logit is NaN
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int j = (i * LNT_W + threadIdx.x) * 4;
+    xv[i] = (float4_t){ninf, ninf, ninf, ninf};
+    if (j + 3 < V) xv[i] = *reinterpret_cast<const float4_t*>(x + j);
+    else
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (j + e < V) xv[i][e] = x[j + e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (j + e == ban_id) xv[i][e] = ninf;
+      const float v = xv[i][e];
+      if (v > tp.best) { tp.second = tp.best; tp.best = v; tp.idx = j + e; }
+      else if (v > tp.second) tp.second = v;
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    AmTop q;
+    q.best = __shfl_xor(tp.best, o, 64);
+    q.idx = __shfl_xor(tp.idx, o, 64);
+    q.second = __shfl_xor(tp.second, o, 64);
+    tp = am_combine(tp, q);
+  }
+  const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+  if (l == 0) { sb[w] = tp.best; si[w] = tp.idx; s2[w] = tp.second; }
+  __syncthreads();
+  AmTop all = {sb[0], si[0], s2[0]};
+#pragma unroll
+  for (int i = 1; i < LNT_W / 64; ++i) all = am_combine(all, (AmTop){sb[i], si[i], s2[i]});
+  if (threadIdx.x == 0) {
+    out[row] = all.idx;
+    if (margin) margin[row] = all.best - all.second;
+  }
+  if (pmax) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s += __expf((xv[i][e] - all.best) * inv_temp);      // -inf (past V, banned) adds exp(-inf) = 0
+    s = block_sum<LNT_W / 64>(s, red);
+    if (threadIdx.x == 0) pmax[row] = 1.f / s;
+  }
+}
+
 extern "C" int mh_argmax_pmax_rows(const float* logits, long ldl, long* out, float* margin, float* pmax, int R, int V,
                                    int ban_id, float inv_temp, hipStream_t stream) {
   if (R <= 0) return MH_OK;
   if (!out || !pmax) return MH_ERR_ARG;
+  if (V <= 8 * LNT_W * 4 && (ldl % 4) == 0 && !((uintptr_t)logits & 15) && inv_temp > 0.f) {
+    hipLaunchKernelGGL(argmax_pmax_wide_kernel, dim3(R), dim3(LNT_W), 0, stream, logits, ldl, out, margin, pmax, V, ban_id, inv_temp);
+    MH_CHECK_LAUNCH();
+    return MH_OK;
+  }
   hipLaunchKernelGGL(argmax_kernel, dim3(R), dim3(LNT), 0, stream, logits, ldl, out, margin, V, ban_id);
   hipLaunchKernelGGL(pmax_kernel, dim3(R), dim3(LNT), 0, stream, logits, ldl, out, pmax, V, ban_id, inv_temp);
   MH_CHECK_LAUNCH();

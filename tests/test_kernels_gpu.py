@@ -908,6 +908,34 @@ def test_clamp_ce_matches_oracle_including_saturation():
     assert relerr(margin.cpu(), t2[:, 0] - t2[:, 1]) < 1e-5
 
 
+@pytest.mark.parametrize("R,V,ban", [(1, 32000, -1), (8, 32000, 2), (3, 1000, 17), (2, 320, -1), (4, 32768, 5)])
+def test_greedy_step_in_one_launch_equals_the_two_scans(R, V, ban):
+    """mh_argmax_pmax_rows with the row in registers (one launch: arg-max, top-1 / top-2 margin, p_max) against the
+    single-workgroup scan kernels it replaces (mh_argmax_rows) and a torch softmax: ids and margins equal, ties included (first
+    index wins, a duplicated maximum gives margin 0, the banned id is -inf), p_max = max softmax over the allowed ids within 1e-6."""
+    g = torch.Generator().manual_seed(900 + R + V)
+    x = torch.randn(R, V, generator=g) * 3
+    x[0, V // 3] = x[0].max() + 1.0
+    x[0, V // 3 + 7] = x[0, V // 3]                         # a tie: the first index wins, margin 0
+    if ban >= 0 and R > 1:
+        x[1, ban] = x[1].max() + 5.0                         # the banned id would have won
+    xd = x.to(DEV)
+    ids0, m0 = ops.argmax_rows(xd, ban_id=ban, want_margin=True)
+    ids = torch.empty(R, dtype=torch.long, device=DEV)
+    mar = torch.empty(R, dtype=torch.float32, device=DEV)
+    pm = torch.empty(R, dtype=torch.float32, device=DEV)
+    for inv_temp in (1.0, 0.7):
+        ops.argmax_pmax_rows(xd, ids, mar, pm, ban_id=ban, inv_temp=inv_temp)
+        assert torch.equal(ids, ids0) and torch.equal(mar, m0)
+        x2 = x.clone()
+        if ban >= 0:
+            x2[:, ban] = -float("inf")
+        assert torch.equal(ids.cpu(), x2.argmax(-1))
+        want = torch.softmax(x2.double() * inv_temp, -1).max(-1).values
+        assert float((pm.cpu().double() - want).abs().max()) < 1e-6
+    assert int(ids[0]) == V // 3 and float(mar[0]) == 0.0
+
+
 def test_adamw_matches_oracle():
     n = 4096 * 3
     p = rnd(n, seed=101)

@@ -227,6 +227,10 @@ int mh_argmax_pmax_rows(const float* logits, long ldl, long* out, float* margin,
    input and the host fetches a step with one copy */
 int mh_decode_record(const long* nxt, const float* margin, const float* pmax, float* rec, long* next_ids, int* step, int R,
                      mh_stream_t s);
+/* the same plus pos[r] += 1 and kvlen[r] += 1 (the decode step's device-resident rotary position and valid-key count, one int per
+   row): the step's three bookkeeping launches as one */
+int mh_decode_advance(const long* nxt, const float* margin, const float* pmax, float* rec, long* next_ids, int* step, int* pos,
+                      int* kvlen, int R, mh_stream_t s);
 
 /* K12 conv stacks of VEInstructorV2 / VETokenizer (networks.py:98-127,159-189) as im2col + mh_gemm_bf16_nt. */
 int mh_im2col_nhwc(const void* x, void* col, int B, int H, int W, int C, int kh, int kw, int pad, int Kpad,

@@ -214,6 +214,30 @@ __global__ void decode_record_kernel(const long* __restrict__ nxt, const float* 
   }
   if (threadIdx.x == 0) *step += 1;
 }
+// The same plus the device-resident position / valid-length counters of the KV-cache decode (one int per row each) advanced by
+// one: the three bookkeeping launches at the end of a token step as one.
+__global__ void decode_advance_kernel(const long* __restrict__ nxt, const float* __restrict__ margin, const float* __restrict__ pmax,
+                                      float* __restrict__ rec, long* __restrict__ next_ids, int* __restrict__ step,
+                                      int* __restrict__ pos, int* __restrict__ kvlen, int R) {
+  for (int r = threadIdx.x; r < R; r += blockDim.x) {
+    const long id = nxt[r];
+    rec[r] = (float)id;
+    rec[R + r] = margin[r];
+    rec[2 * R + r] = pmax[r];
+    next_ids[r] = id;
+    pos[r] += 1;
+    kvlen[r] += 1;
+  }
+  if (threadIdx.x == 0) *step += 1;
+}
+extern "C" int mh_decode_advance(const long* nxt, const float* margin, const float* pmax, float* rec, long* next_ids, int* step,
+                                 int* pos, int* kvlen, int R, hipStream_t stream) {
+  if (R <= 0) return MH_OK;
+  if (!nxt || !margin || !pmax || !rec || !next_ids || !step || !pos || !kvlen) return MH_ERR_ARG;
+  hipLaunchKernelGGL(decode_advance_kernel, dim3(1), dim3(64), 0, stream, nxt, margin, pmax, rec, next_ids, step, pos, kvlen, R);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
 extern "C" int mh_decode_record(const long* nxt, const float* margin, const float* pmax, float* rec, long* next_ids, int* step,
                                 int R, hipStream_t stream) {
   if (R <= 0) return MH_OK;

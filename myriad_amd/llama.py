@@ -477,9 +477,7 @@ class LlamaHIP:
                 else:
                     ops.gemm(hn, self.lm_head, out=ws["logits"])
             ops.argmax_pmax_rows(ws["logits"], ws["nxt"], ws["mar"], ws["pmx"], ban_id=ban, inv_temp=inv_temp)
-            ops.decode_record(ws["nxt"], ws["mar"], ws["pmx"], ws["rec"], ws["ids"], ws["step"])
-            ops.add_i32_(ws["pos"], 1)
-            ops.add_i32_(ws["kvlen"], 1)
+            ops.decode_advance(ws["nxt"], ws["mar"], ws["pmx"], ws["rec"], ws["ids"], ws["step"], ws["pos"], ws["kvlen"])
 
         def launch(ban):
             """Enqueue one token step: a replay of the captured graph when there is one."""

@@ -773,6 +773,13 @@ def decode_record(nxt, margin, pmax, rec, next_ids, step_dev):
                "mh_decode_record")
 
 
+def decode_advance(nxt, margin, pmax, rec, next_ids, step_dev, pos, kvlen):
+    """decode_record() and pos += 1, kvlen += 1 in one launch (the end of a KV-cache token step)."""
+    R = nxt.numel()
+    _lib.check(_L().mh_decode_advance(_p(nxt), _p(margin), _p(pmax), _p(rec), _p(next_ids), _p(step_dev), _p(pos), _p(kvlen), R,
+                                      _s()), "mh_decode_advance")
+
+
 # --------------------------------------------------------------------------- conv stack pieces
 def im2col(x_nhwc: torch.Tensor, kh: int, kw: int, pad: int, bias_col: bool = True):
     """[B*OH*OW, Kpad] bf16 patches, (ky, kx, c) order; with bias_col a column of ones follows the K patch columns (the bias

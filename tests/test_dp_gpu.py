@@ -141,3 +141,28 @@ def test_accum_grad_iters_sums_the_window_and_steps_once():
     for k in ("p", "m", "v"):
         assert torch.equal(a[k], b[k]), k
     assert a["steps"] == b["steps"] and a["steps"]["VETokenizer"] == 2 and a["steps"]["VEInstructor"] == 1
+
+
+def test_early_adamw_of_the_tokenizer_on_the_leaf_stream_is_the_same_update(monkeypatch):
+    """Single-process train_step updates the map tokenizer (91 % of the trainable parameters) on the leaf side stream as soon as
+    its backward is done, beside the Q-Former backward, instead of at the tail of the step (MYRIAD_EARLY_ADAMW=0: all modules at
+    the tail).  Same kernel, same inputs: three steps with ragged prompt stages end with bit-identical parameters, moments and
+    per-module step counts, and a step whose stage skips the tokenizer leaves it untouched either way."""
+    from tests import dp_common as C
+    dev = torch.device("cuda:0")
+    stages = [1, 2, 0]                                        # step 1 (stage 2): the tokenizer is unused
+    snaps = []
+    for early in ("1", "0"):
+        monkeypatch.setenv("MYRIAD_EARLY_ADAMW", early)
+        m, cfg = C.build_model(dev)
+        m.lora.base_seed = 11
+        for i in range(3):
+            m.fixed_stage = stages[i]
+            nxt = C.batch(0, i + 1, cfg["vocab"], dev) if i < 2 else None
+            m.train_step(C.batch(0, i, cfg["vocab"], dev), C.LRS[i], 0.05, next_samples=nxt)
+        m.finish_update()
+        snaps.append(C.snapshot(m))
+    a, b = snaps
+    for k in ("p", "m", "v"):
+        assert torch.equal(a[k], b[k]), k
+    assert a["steps"] == b["steps"] and a["steps"]["VETokenizer"] == 2 and a["steps"]["lora"] == 3

@@ -408,6 +408,8 @@ int mh_target_arch(void); /* 950 */
  *                       forward (mh_gemm_residual_rmsnorm_lora / mh_rmsnorm_lora_fwd)
  *   attn_full (1)       mh_attn_fwd without mask / bias and with Sk <= 288, head dim in (32, 96]: one workgroup stages the whole
  *                       K and V of a (batch, head) (attn_full.hip) instead of 64x64 tiles; 0 = the tiled kernel
+ *   lora_wgrad_mfma (1) mh_lora_wgrad at r = 8, D % 128 == 0: the sums over token rows as MFMA products (per-row scalars as a bf16 head +
+ *                       bf16 remainder, fp32 accumulation); 0 = the thread-per-column fp32 kernel
  * mh_set_option returns the previous value (0 / 1) or MH_ERR_ARG (unknown name, value not 0 / 1); mh_get_option the current
  * value or MH_ERR_ARG.  Not thread-safe against concurrent launches. */
 int mh_set_option(const char* name, int value);

@@ -43,6 +43,7 @@ enum MhOpt {
   MH_OPT_GEMM256_IMPL,      // 1: hand-scheduled 64-deep loop (gemm_x4.hip), 0: the eight-wave fallback kernel (gemm_256.hip)
   MH_OPT_LORA_NORM_FUSED,   // LoRA dx correction + input-norm backward / LoRA down + norm forward as one kernel each
   MH_OPT_ATTN_FULL,         // whole-sequence forward attention (attn_full.hip) for unmasked Sk <= 288, head dim <= 96
+  MH_OPT_LORA_WGRAD_MFMA,   // LoRA weight gradients as MFMA products (r = 8, D % 128 == 0); 0: the thread-per-column kernel
   MH_OPT_COUNT
 };
 int mh_opt(int id);

@@ -5,12 +5,13 @@
 //   lora_down : border[m, j] = s * sum_d keep(m,d) x[m,d] A[j,d]                  (block-per-row reductions)
 //   lora_dx   : dxn[m,d] = dx_base[m,d] + keep(m,d) * s * sum_j dborder[m,j] bf16(A[j,d])   (elementwise; the forward multiplied by bf16(A))
 //   lora_wgrad: dA[j,d] = sum_m s dborder[m,j] keep(m,d) x[m,d] ; dB_q[d,j] = sum_m dq[m,d] border[m,j] ; dB_v likewise
-//               (thread-per-column partial sums over row chunks + fixed-order reduce: deterministic)
+//               (partial sums over row chunks -- MFMA products at r = 8, else thread-per-column -- + fixed-order reduce: deterministic)
 //   lora_refresh_border: writes bf16(B_q), bf16(B_v) into the borders of W_ext and W_ext^T.
 // keep(m,d) = hash(seed, m*D+d) >= p ? 1/(1-p) : 0  -- regenerated, never stored.  R2 = 2r (q then v), r in {8,16}.
 // peft gives q_proj and v_proj their own nn.Dropout, i.e. independent masks: rows j < r of A (q) see keep(seed, .), rows
 // j >= r (v) see the second draw of the same hash (seed with bit 63 set; common.h dropout_keep_pair).
 #include "common.h"
+#include <stdint.h>
 #include <stdlib.h>
 
 // The 64-column border holds G = 64 / R2 GROUPS of R2 columns.  lora_down splits D into G ranges, one workgroup column per
@@ -470,18 +471,155 @@ __global__ __launch_bounds__(LR_WG_NT) void lora_wgrad_partial_kernel(
       }
   }
 }
+// The same partial sums as MFMA work (r = 8, D % 128 == 0): the sums over token rows are [D x rows] . [rows x 16] products.  A
+// workgroup owns 128 columns of one row chunk; 32 rows at a time it stages x (twice: with q's and with v's dropped elements
+// zeroed -- exact; 1/(1-p) multiplies the finished sum), dq and dv key-major in LDS, reads them as the A operand through the
+// gfx950 transpose read, and multiplies by the 16 per-row scalars (s d(border); the border summed over its groups), each split
+// into a bf16 head and a bf16 remainder so that the products carry ~16 mantissa bits of the scalar (fp32 accumulation).  The
+// thread-per-column form above spent its time in 2 * R2 dependent FMAs per element; here the kernel is the loads.
+#define LWM_CB 128                 // columns per workgroup
+#define LWM_RS (LWM_CB + 16)       // image row stride (elements): 288 B = 72 dwords, consecutive rows 8 banks apart
+#define LWM_SS 40                  // row stride of the scalar images [16][32]
+#define LWM_RC 16                  // row chunks (LWM_RC * D / LWM_CB = 512 workgroups at D = 4096)
+typedef __attribute__((address_space(3))) short4_t lw_lds_s4;
+__device__ __forceinline__ short8_t lw_frag_tr(const bf16_t* img, int jd, int lr, int lg) {
+  const bf16_t* p = img + (4 * lg + (lr >> 2)) * LWM_RS + 16 * jd + 4 * (lr & 3);
+  const short4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lw_lds_s4*)p);
+  const short4_t b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lw_lds_s4*)(p + 16 * LWM_RS));
+  return (short8_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+// the B operand that goes with it: lane (j, lg) holds rows {4 lg .. +3} U {16 + 4 lg .. +3} of scalar column j
+__device__ __forceinline__ short8_t lw_frag_sc(const bf16_t* sc, int lr, int lg) {
+  const short4_t a = *reinterpret_cast<const short4_t*>(sc + lr * LWM_SS + 4 * lg);
+  const short4_t b = *reinterpret_cast<const short4_t*>(sc + lr * LWM_SS + 16 + 4 * lg);
+  return (short8_t){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+__global__ __launch_bounds__(256) void lora_wgrad_mfma_kernel(
+    const bf16_t* __restrict__ x, long ldx, const float* __restrict__ dx_ext, long ldg, const bf16_t* __restrict__ dq,
+    const bf16_t* __restrict__ dv, long ldq, const bf16_t* __restrict__ border, long ldb, float* __restrict__ pA,
+    float* __restrict__ pBq, float* __restrict__ pBv, int M, int D, float s, float p, unsigned long long seed) {
+  constexpr int R2 = 16, r = 8;
+  __shared__ __attribute__((aligned(16))) bf16_t img[4][32 * LWM_RS];    // x (q mask), x (v mask), dq, dv
+  __shared__ __attribute__((aligned(16))) bf16_t sc[4][16 * LWM_SS];     // sg head / remainder, st head / remainder, [j][row]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, lr = lane & 15, lg = lane >> 4;
+  const int d0 = blockIdx.x * LWM_CB;
+  const int chunk = blockIdx.y;
+  const int rows_per = (M + LWM_RC - 1) / LWM_RC;
+  const int m0 = chunk * rows_per;
+  const int m1 = (m0 + rows_per) < M ? (m0 + rows_per) : M;
+  const float ik = 1.f / (1.f - p);
+  // staging role: row (tid >> 3) of the 32, 16 columns from 16 * (tid & 7); scalars: the same row, columns 2 * (tid & 7), +1
+  const int srow = tid >> 3, scol = (tid & 7) * 16, sj = (tid & 7) * 2;
+  short8_t xr[2], qr[2], vr[2];
+  float sgr[2], str[2];
+  auto load_step = [&](int mb) {
+    const int m = mb + srow;
+    const short8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    xr[0] = xr[1] = qr[0] = qr[1] = vr[0] = vr[1] = z;
+    sgr[0] = sgr[1] = str[0] = str[1] = 0.f;
+    if (m < m1) {
+      const bf16_t* xp = x + (long)m * ldx + d0 + scol;
+      const bf16_t* qp = dq + (long)m * ldq + d0 + scol;
+      const bf16_t* vp = dv + (long)m * ldq + d0 + scol;
+      xr[0] = *reinterpret_cast<const short8_t*>(xp);
+      xr[1] = *reinterpret_cast<const short8_t*>(xp + 8);
+      qr[0] = *reinterpret_cast<const short8_t*>(qp);
+      qr[1] = *reinterpret_cast<const short8_t*>(qp + 8);
+      vr[0] = *reinterpret_cast<const short8_t*>(vp);
+      vr[1] = *reinterpret_cast<const short8_t*>(vp + 8);
+      sgr[0] = dx_ext[(long)m * ldg + D + sj];
+      sgr[1] = dx_ext[(long)m * ldg + D + sj + 1];
+#pragma unroll
+      for (int g = 0; g < LORA_BORDER / R2; ++g) {                 // the border's groups add up to s * t
+        str[0] += bf2f(border[(long)m * ldb + g * R2 + sj]);
+        str[1] += bf2f(border[(long)m * ldb + g * R2 + sj + 1]);
+      }
+    }
+  };
+  auto store_step = [&](int mb) {
+    const int m = mb + srow;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      short8_t xq = xr[h], xv = xr[h];
+      if (p > 0.f) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          float kq, kv;
+          dropout_keep_pair(seed, (unsigned long long)((long)m * D + d0 + scol + 8 * h + e), p, ik, kq, kv);
+          if (kq == 0.f) xq[e] = 0;
+          if (kv == 0.f) xv[e] = 0;
+        }
+      }
+      const int o = srow * LWM_RS + scol + 8 * h;
+      *reinterpret_cast<short8_t*>(&img[0][o]) = xq;
+      *reinterpret_cast<short8_t*>(&img[1][o]) = xv;
+      *reinterpret_cast<short8_t*>(&img[2][o]) = qr[h];
+      *reinterpret_cast<short8_t*>(&img[3][o]) = vr[h];
+    }
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const float g = s * sgr[h], t = str[h];
+      const bf16_t gh = f2bf(g), th = f2bf(t);
+      const int o = (sj + h) * LWM_SS + srow;
+      sc[0][o] = gh;
+      sc[1][o] = f2bf(g - bf2f(gh));
+      sc[2][o] = th;
+      sc[3][o] = f2bf(t - bf2f(th));
+    }
+  };
+  constexpr int NJD = LWM_CB / 16 / 4;             // 16-column blocks per wave
+  float4_t aq[NJD], av[NJD], bq[NJD], bv[NJD];
+#pragma unroll
+  for (int i = 0; i < NJD; ++i) aq[i] = av[i] = bq[i] = bv[i] = (float4_t){0.f, 0.f, 0.f, 0.f};
+  load_step(m0);
+  for (int mb = m0; mb < m1; mb += 32) {
+    __syncthreads();                               // the previous step's operand reads are done
+    store_step(mb);
+    __syncthreads();
+    if (mb + 32 < m1) load_step(mb + 32);          // in flight under the products
+    const short8_t gh = lw_frag_sc(sc[0], lr, lg), gl = lw_frag_sc(sc[1], lr, lg);
+    const short8_t th = lw_frag_sc(sc[2], lr, lg), tl = lw_frag_sc(sc[3], lr, lg);
+#pragma unroll
+    for (int i = 0; i < NJD; ++i) {
+      const int jd = wave * NJD + i;
+      const short8_t fq = lw_frag_tr(img[0], jd, lr, lg), fv = lw_frag_tr(img[1], jd, lr, lg);
+      const short8_t fdq = lw_frag_tr(img[2], jd, lr, lg), fdv = lw_frag_tr(img[3], jd, lr, lg);
+      aq[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq, gh, aq[i], 0, 0, 0);
+      aq[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq, gl, aq[i], 0, 0, 0);
+      av[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, gh, av[i], 0, 0, 0);
+      av[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv, gl, av[i], 0, 0, 0);
+      bq[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fdq, th, bq[i], 0, 0, 0);
+      bq[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fdq, tl, bq[i], 0, 0, 0);
+      bv[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fdv, th, bv[i], 0, 0, 0);
+      bv[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fdv, tl, bv[i], 0, 0, 0);
+    }
+  }
+  // accumulator of lane (j = lr, lg): columns d = 16 jd + 4 lg + e of scalar column j.  Rows j < r of A belong to q (x under q's
+  // mask), the others to v; the border column j < r multiplies dq, the others dv.
+#pragma unroll
+  for (int i = 0; i < NJD; ++i) {
+    const int d = d0 + 16 * (wave * NJD + i) + 4 * lg;
+    const float4_t a = lr < r ? aq[i] : av[i];
+    *reinterpret_cast<float4_t*>(pA + ((long)chunk * R2 + lr) * D + d) = (float4_t){a[0] * ik, a[1] * ik, a[2] * ik, a[3] * ik};
+    float* pb = lr < r ? pBq : pBv;
+    const float4_t b = lr < r ? bq[i] : bv[i];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pb[((long)chunk * D + d + e) * r + (lr & (r - 1))] = b[e];
+  }
+}
+
 __global__ void lora_wgrad_reduce_kernel(const float* __restrict__ pA, const float* __restrict__ pBq,
                                          const float* __restrict__ pBv, float* __restrict__ dA, float* __restrict__ dBq,
-                                         float* __restrict__ dBv, int nA, int nB) {
+                                         float* __restrict__ dBv, int nA, int nB, int nch) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < nA) {
     float s = 0.f;
-    for (int c = 0; c < LR_CH; ++c) s += pA[(long)c * nA + i];
+    for (int c = 0; c < nch; ++c) s += pA[(long)c * nA + i];
     dA[i] = s;
   }
   if (i < nB) {
     float s = 0.f, t = 0.f;
-    for (int c = 0; c < LR_CH; ++c) {
+    for (int c = 0; c < nch; ++c) {
       s += pBq[(long)c * nB + i];
       t += pBv[(long)c * nB + i];
     }
@@ -614,14 +752,24 @@ extern "C" int mh_lora_wgrad(const void* x, long ldx, const float* dx_ext, long 
   float* pBq = pA + (long)LR_CH * R2_ * D;
   float* pBv = pBq + (long)LR_CH * D * r;
   if ((D % 4) != 0 || (ldx % 4) != 0 || (ldq % 4) != 0) return MH_ERR_ARG;
-  const dim3 grid((D / 4 + LR_WG_NT - 1) / LR_WG_NT, LR_CH);
-  LORA_DISPATCH(R2_, hipLaunchKernelGGL(lora_wgrad_partial_kernel<R2>, grid, dim3(LR_WG_NT), 0, stream, (const bf16_t*)x, ldx,
-                                        dx_ext, ldg, (const bf16_t*)dq, (const bf16_t*)dv, ldq, (const bf16_t*)border, ldb,
-                                        pA, pBq, pBv, M, D, s, p, seed));
+  int nch = LR_CH;
+  const bool al16 = (((uintptr_t)x | (uintptr_t)dq | (uintptr_t)dv) & 15) == 0 && (ldx % 8) == 0 && (ldq % 8) == 0 && (ldg % 2) == 0;
+  if (R2_ == 16 && (D % LWM_CB) == 0 && al16 && mh_opt(MH_OPT_LORA_WGRAD_MFMA)) {
+    nch = LWM_RC;
+    pBq = pA + (long)nch * R2_ * D;
+    pBv = pBq + (long)nch * D * r;
+    hipLaunchKernelGGL(lora_wgrad_mfma_kernel, dim3(D / LWM_CB, LWM_RC), dim3(256), 0, stream, (const bf16_t*)x, ldx, dx_ext, ldg,
+                       (const bf16_t*)dq, (const bf16_t*)dv, ldq, (const bf16_t*)border, ldb, pA, pBq, pBv, M, D, s, p, seed);
+  } else {
+    const dim3 grid((D / 4 + LR_WG_NT - 1) / LR_WG_NT, LR_CH);
+    LORA_DISPATCH(R2_, hipLaunchKernelGGL(lora_wgrad_partial_kernel<R2>, grid, dim3(LR_WG_NT), 0, stream, (const bf16_t*)x, ldx,
+                                          dx_ext, ldg, (const bf16_t*)dq, (const bf16_t*)dv, ldq, (const bf16_t*)border, ldb,
+                                          pA, pBq, pBv, M, D, s, p, seed));
+  }
   MH_CHECK_LAUNCH();
   const int nA = R2_ * D, nB = D * r;
   hipLaunchKernelGGL(lora_wgrad_reduce_kernel, dim3((nA + 255) / 256), dim3(256), 0, stream, pA, pBq, pBv, dA, dBq, dBv, nA,
-                     nB);
+                     nB, nch);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

@@ -580,6 +580,51 @@ def test_lora_backward_fused_with_the_qkv_dgrad_is_bit_identical():
     assert torch.equal(outs[0][1], outs[1][1]) and float(outs[0][1].abs().sum()) > 0
 
 
+@pytest.mark.parametrize("M,p", [(1184, 0.05), (1184, 0.0), (148, 0.05), (37, 0.05), (5, 0.05)])
+def test_lora_weight_gradients_as_mfma_products(M, p):
+    """mh_lora_wgrad's MFMA kernel (option lora_wgrad_mfma, the default at r = 8) against the thread-per-column kernel it replaces
+    and against float64 sums over the regenerated keep masks.  The MFMA form rounds nothing but the per-row scalars, and those to
+    a bf16 head + bf16 remainder (~2^-16): the two kernels agree to 2e-5 of the gradient's scale, both to 1e-4 of float64's."""
+    from myriad_amd import _lib as L
+    from myriad_amd.lora import BORDER, V_TAG, LoraQV, lora_param_specs
+    from myriad_amd.myriad import ParamStore
+    D, r, s = 4096, 8, 2.0
+    gen = torch.Generator().manual_seed(177)
+    dqkv = (torch.randn(M, 3 * D, generator=gen) * 0.02).to(DEV).to(torch.bfloat16)
+    x_ext = (torch.randn(M, D + BORDER, generator=gen) * 0.5).to(DEV).to(torch.bfloat16)
+    dx_ext = (torch.randn(M, D + BORDER, generator=gen) * 0.1).to(DEV)
+    seed = 987654321
+    outs = {}
+    for mfma in (0, 1):
+        L.load().mh_set_option(b"lora_wgrad_mfma", mfma)
+        try:
+            st = ParamStore(lora_param_specs(1, D, r), DEV)
+            lora = LoraQV(1, D, r, 16.0, 0.05, st.p, st.g, DEV)
+            assert lora.s == s
+            st.flat_g.zero_()
+            lora._wgrad(0, (dx_ext, dx_ext.data_ptr(), dx_ext.stride(0)), dqkv, x_ext, p, seed)
+            torch.cuda.synchronize()
+            outs[mfma] = [st.g[n].double().clone() for n in lora.names(0)]
+        finally:
+            L.load().mh_set_option(b"lora_wgrad_mfma", 1)
+    x = x_ext[:, :D].double()
+    if p > 0:
+        ones = torch.ones(M, D, dtype=torch.bfloat16, device=DEV)
+        kq = (ops.dropout_bf16(ones, p, seed) != 0).double() / (1 - p)
+        kv = (ops.dropout_bf16(ones, p, seed ^ V_TAG) != 0).double() / (1 - p)
+    else:
+        kq = kv = torch.ones(M, D, dtype=torch.float64, device=DEV)
+    sg = s * dx_ext[:, D:D + 2 * r].double()                                  # [M, 2r]
+    st_ = x_ext[:, D:].double().reshape(M, BORDER // (2 * r), 2 * r).sum(1)   # the border's groups add up to s * t
+    want = [sg[:, :r].T @ (x * kq), sg[:, r:].T @ (x * kv),
+            dqkv[:, :D].double().T @ st_[:, :r], dqkv[:, 2 * D:].double().T @ st_[:, r:]]
+    for a, b, w in zip(outs[0], outs[1], want):
+        scale = float(w.abs().max())
+        assert scale > 0
+        assert float((a - b).abs().max()) <= 2e-5 * scale
+        assert float((b - w).abs().max()) <= 1e-4 * scale and float((a - w).abs().max()) <= 1e-4 * scale
+
+
 @pytest.mark.parametrize("M,K,p", [(1184, 12288, 0.05), (1184, 12288, 0.0), (148, 12288, 0.05), (37, 12288, 0.05)])
 def test_lora_dx_and_the_input_norm_backward_in_one_kernel_are_bit_identical(M, K, p):
     """mh_gemm_lora_rmsnorm_bwd (LoRA dx correction + the input RMSNorm's backward as ONE kernel that also sums the dgrad's

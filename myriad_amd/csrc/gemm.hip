@@ -128,7 +128,8 @@ __global__ __launch_bounds__(NW * 64, MINB * NW / 4) void gemm_nt_kernel(const b
   const int nt_all = K / BK;
   const int kt0 = blockIdx.y * kt_per_split;
   const int nt = (nt_all - kt0) < kt_per_split ? (nt_all - kt0) : kt_per_split;
-  if (gridDim.y > 1) Cv = reinterpret_cast<float*>(Cv) + blockIdx.y * split_stride;
+  if (gridDim.y > 1)   // the partial slab of this split: fp32, or bf16 when the launch asks for bf16 output (run_splitk)
+    Cv = reinterpret_cast<char*>(Cv) + blockIdx.y * split_stride * ((flags & MH_GEMM_OUT_F32) ? 4 : 2);
 
   auto issue_dma = [&](int t, int stage) {
     char* sA = smem + stage * STAGE;
@@ -453,7 +454,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const void* __r
   }
 }
 
-// Slabs of the 256x256 kernel are bf16 (MYRIAD_SLAB_BF16=0: fp32): these are the K <= 22016 forward / dgrad products of the
+// Slabs of the 256x256 kernel and of the 160-row tiles are bf16 (MYRIAD_SLAB_BF16=0: fp32): these are the K <= 22016 forward / dgrad products of the
 // LLaMA and ViT Linears, whose results are rounded to bf16 (or added to the fp32 residual stream) anyway; the partial sums cost
 // 2 x 4 B per output element per split in fp32 -- 9 GB per step at batch 8.  The 128x128 kernel's slabs (weight gradients: long
 // cancelling reductions over tokens) stay fp32.  *slab_bf16 tells the caller which it got.
@@ -464,8 +465,10 @@ static int run_splitk(const GemmArgs& g0, int splits, float* ws, hipStream_t str
   if (splits > nt) splits = nt;
   const int tps = (nt + splits - 1) / splits;
   splits = (nt + tps - 1) / tps;
-  const bool big = ((g0.flags >> MH_GEMM_VARIANT_SHIFT) & 15) == 12;
-  const int sbf = (big && g_slab_bf16 && (g0.N % 8) == 0) ? 1 : 0;
+  const int var0 = (g0.flags >> MH_GEMM_VARIANT_SHIFT) & 15;
+  const bool big = var0 == 12;
+  const bool row_tile = var0 == 14 || var0 == 15;       // the 160-row tiles (batch-1 step): the same forward / dgrad products
+  const int sbf = ((big || row_tile) && g_slab_bf16 && (g0.N % 8) == 0) ? 1 : 0;
   if (slab_bf16) *slab_bf16 = sbf;
   GemmArgs g = g0;
   g.C = (void*)ws; g.ldc = g0.N; g.bias = nullptr; g.residual = nullptr; g.ldr = 0;

@@ -91,10 +91,11 @@ def test_gemm_splitk_wgrad_shapes(M, N, K):
 
 
 def slab_tol(M, N, K, tight):
-    """Accuracy bound of an automatically split product against fp32 math: the 256x256 kernel's partial slabs are bf16 (one
-    2^-9 rounding per partial sum, csrc/gemm.hip run_splitk) -- the bit-identity of fused and unfused forms is unaffected."""
+    """Accuracy bound of an automatically split product against fp32 math: the partial slabs of the 256x256 kernel and of the
+    160-row tiles are bf16 (one 2^-9 rounding per partial sum, csrc/gemm.hip run_splitk) -- the bit-identity of fused and unfused
+    forms is unaffected."""
     kernel, splits = ops.gemm_plan(M, N, K)
-    return 4e-3 if (kernel == 2 and splits > 1) else tight
+    return 4e-3 if (kernel in (2, 4, 5) and splits > 1) else tight
 
 
 def _slab_hook():

@@ -180,6 +180,11 @@ int mh_lora_down(const void* x, long ldx, const float* A, void* border, long ldo
                  unsigned long long seed, mh_stream_t st);
 int mh_lora_dx(const float* dx_ext, long ld, const float* A, float* out, int M, int D, int R2, float s, float p,
                unsigned long long seed, mh_stream_t st);
+/* Head of a single-token decode step with LoRA attached (M <= 2 rows, no dropout): x_ext[:, :D] = bf16(rmsnorm(h; w, eps)) and
+ * x_ext[:, D:D+64] = its LoRA border, one launch with the bits of mh_rmsnorm_fwd + mh_lora_down (LlamaRMSNorm,
+ * modeling_llama.py:66-74, in front of the peft q_proj / v_proj).  MH_ERR_UNSUPPORTED for M > 2 or D > 4096. */
+int mh_rmsnorm_lora_down(const float* h, long ldh, const float* norm_w, float eps, const float* A, void* x_ext, long ldx, int M,
+                         int D, int R2, float s, mh_stream_t st);
 /* The qkv dgrad with the LoRA border, [M, D+64] = dqkv . [W_qkv | B_ext]^T-layout operand (myriad.py:170-180 under autograd),
  * and the LoRA dx correction that reads it, in one call: when mh_gemm_plan(M, D+64, K) splits K the correction kernel sums the
  * fp32 partial slabs itself (no reduce launch, same bits) and writes the summed border d(s*t) [M, 64] to border_out; otherwise
@@ -404,8 +409,7 @@ int mh_target_arch(void); /* 950 */
  *   attn_bwd_split (1)  two workgroups per (batch, head) in mh_attn_rope_bwd when B*H <= 128
  *   gemm_zero_pad (1)   rows past M / N of a 256x256 tile read as zeros; 0 = as copies of the last row
  *   gemm256_impl (1)    plan kernel 2 = gemm_x8_kernel; 0 = gemm_256_kernel
- *   lora_norm_fused (1) LoRA dx + input-norm backward as one kernel (mh_gemm_lora_rmsnorm_bwd), LoRA down inside the norm
- *                       forward (mh_gemm_residual_rmsnorm_lora / mh_rmsnorm_lora_fwd)
+ *   lora_norm_fused (1) LoRA dx + input-norm backward as one kernel (mh_gemm_lora_rmsnorm_bwd); 0 = the two launches
  *   attn_full (1)       mh_attn_fwd without mask / bias and with Sk <= 288, head dim in (32, 96]: one workgroup stages the whole
  *                       K and V of a (batch, head) (attn_full.hip) instead of 64x64 tiles; 0 = the tiled kernel
  *   lora_wgrad_mfma (1) mh_lora_wgrad at r = 8, D % 128 == 0: the sums over token rows as MFMA products (per-row scalars as a bf16 head +

@@ -30,17 +30,56 @@
 // A is read once per 16 rows (the first version: a block per row, all 256 KiB of A per row, 16 block reductions, 24 us).
 // A enters the MFMA in bf16 like every other GEMM operand on the path (the border it produces is itself a bf16 operand).
 #define LD_NW 8
-template <int R2>
+// NORM = 1 (the single-token decode step with LoRA attached, M <= 2 rows, p = 0): x is not given -- every workgroup first builds the
+// RMS-normalised rows of the f32 residual stream h itself (LDS, [M][D] bf16; rmsnorm_fwd_kernel's summation order and expression,
+// as gemv.hip's gemv_pro_kernel does), writes ITS range of columns to x_ext (the operand of the bordered qkv product) and then
+// runs the same products on the LDS copy: the bits of mh_rmsnorm_fwd + mh_lora_down in one launch.
+template <int R2, int NORM = 0>
 __global__ __launch_bounds__(LD_NW * 64) void lora_down_kernel(const bf16_t* __restrict__ x, long ldx,
                                                                 const float* __restrict__ A, bf16_t* __restrict__ out,
                                                                 long ldo, int M, int D, float s, float p,
-                                                                unsigned long long seed) {
+                                                                unsigned long long seed, const float* __restrict__ hres = nullptr,
+                                                                long ldh = 0, const float* __restrict__ norm_w = nullptr,
+                                                                float eps = 0.f, bf16_t* __restrict__ xn_out = nullptr) {
   constexpr int NJ = R2 / 16;
   __shared__ float red[LD_NW][NJ][256];
+  extern __shared__ __attribute__((aligned(16))) char ld_dyn[];      // NORM: the normalised rows
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, lr = lane & 15, lg = lane >> 4;
   const int m0 = blockIdx.x * 16;
   int mrow = m0 + lr;
   mrow = mrow < M ? mrow : M - 1;
+  if (NORM) {
+    __shared__ float bred[LD_NW];
+    bf16_t* xs = reinterpret_cast<bf16_t*>(ld_dyn);
+    const int tid = threadIdx.x;
+    const int c0 = blockIdx.y * (D / gridDim.y), c1 = c0 + D / gridDim.y;     // the columns this workgroup publishes
+    for (int m = 0; m < M; ++m) {
+      const float* xr = hres + (size_t)m * ldh;
+      float4_t hv[4];                                              // D <= 4096 (checked by the launcher)
+      float ss = 0.f;
+      int c = 0;
+      if (tid < 256)
+        for (int i = tid * 4; i < D; i += 1024, ++c) {
+          hv[c] = *reinterpret_cast<const float4_t*>(xr + i);
+          ss += hv[c][0] * hv[c][0] + hv[c][1] * hv[c][1] + hv[c][2] * hv[c][2] + hv[c][3] * hv[c][3];
+        }
+      ss = block_sum<LD_NW>(ss, bred);                             // waves 4.. add exact zeros: the sum of rmsnorm_fwd_kernel
+      const float rr = rsqrtf(ss / D + eps);
+      c = 0;
+      if (tid < 256)
+        for (int i = tid * 4; i < D; i += 1024, ++c) {
+          const float4_t g = *reinterpret_cast<const float4_t*>(norm_w + i);
+          uint2 pk;
+          pk.x = pack_bf2(g[0] * (hv[c][0] * rr), g[1] * (hv[c][1] * rr));
+          pk.y = pack_bf2(g[2] * (hv[c][2] * rr), g[3] * (hv[c][3] * rr));
+          *reinterpret_cast<uint2*>(xs + (size_t)m * D + i) = pk;
+          if (i >= c0 && i < c1) *reinterpret_cast<uint2*>(xn_out + (size_t)m * ldx + i) = pk;
+        }
+    }
+    __syncthreads();
+    x = xs;
+    ldx = D;
+  }
   const float ik = 1.f / (1.f - p);
   constexpr int r = R2 / 2;
   float4_t acc[NJ], accv[NJ];                      // acc: x under the q mask, accv: x under the v mask
@@ -680,6 +719,23 @@ extern "C" int mh_lora_down(const void* x, long ldx, const float* A, void* borde
   while (G > 1 && (D % (32 * G)) != 0) G >>= 1;
   LORA_DISPATCH(R2_, hipLaunchKernelGGL(lora_down_kernel<R2>, dim3((M + 15) / 16, G), dim3(LD_NW * 64), 0, stream,
                                         (const bf16_t*)x, ldx, A, (bf16_t*)border, ldo, M, D, s, p, seed));
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+
+// x_ext[:, :D] = bf16(rmsnorm(h; w, eps)) and x_ext[:, D:D+64] = the LoRA border of those rows (no dropout), M <= 2 rows: the head of a
+// single-token decode step with LoRA attached.  MH_ERR_UNSUPPORTED for more rows / wider models: the caller runs the two launches.
+extern "C" int mh_rmsnorm_lora_down(const float* h, long ldh, const float* norm_w, float eps, const float* A, void* x_ext, long ldx,
+                                    int M, int D, int R2_, float s, hipStream_t stream) {
+  if (M <= 0) return MH_OK;
+  if (!h || !norm_w || !A || !x_ext || D % 32 || ldx % 8 || ldh % 4 || ldx < D + LORA_BORDER || R2_ <= 0 || R2_ > LORA_BORDER)
+    return MH_ERR_ARG;
+  if (M > 2 || D > 4096) return MH_ERR_UNSUPPORTED;
+  int G = LORA_BORDER / R2_;
+  while (G > 1 && (D % (32 * G)) != 0) G >>= 1;
+  bf16_t* xe = (bf16_t*)x_ext;
+  LORA_DISPATCH(R2_, hipLaunchKernelGGL((lora_down_kernel<R2, 1>), dim3(1, G), dim3(LD_NW * 64), (size_t)M * D * 2, stream,
+                                        (const bf16_t*)nullptr, ldx, A, xe + D, ldx, M, D, s, 0.f, 0ULL, h, ldh, norm_w, eps, xe));
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

@@ -304,17 +304,26 @@ class LlamaHIP:
                 return ops.gemv_packed(x, packed[li]["wqkv" if name.startswith("wqkv") else name], **kw)
             return ops.gemm(x, self.layers[li][name], **kw)
 
-        # Single-token step on the packed copies without LoRA: four launches per layer instead of nine -- the two RMSNorms
+        # Single-token step on the packed copies: four launches per layer instead of nine -- the two RMSNorms
         # and the SiLU gate are rebuilt by every workgroup of the product that consumes them (mh_gemv_packed_rmsnorm /
         # _silu), rotary + KV append ride the attention launch (mh_attn_decode_rope); each fused form is bit-identical
         # to the launches it replaces (tests/test_kernels_gpu.py), MYRIAD_DECODE_FUSED=0 keeps the separate launches.
-        fused = packed is not None and self.lora is None and self.decode_fused
+        # With LoRA attached the qkv product takes the bordered operand [xn | s A xn]: the norm and the LoRA down projection are
+        # one launch (LoraQV.norm_border, <= 2 rows), the bordered packed weight the next -- five launches per layer become six.
+        fused = packed is not None and self.decode_fused
         for li, (L, cache) in enumerate(zip(self.layers, caches)):
             if fused:
                 P = packed[li]
-                qkv = ops.gemv_packed_rmsnorm(h, L["ln1"], self.eps, P["wqkv"])
-                if qkv is None:
-                    qkv = ops.gemv_packed(ops.rmsnorm_fwd(h, L["ln1"], self.eps), P["wqkv"])
+                if self.lora is not None:
+                    x_ext = self.lora.x_ext(li, M)
+                    if not self.lora.norm_border(li, h, L["ln1"], self.eps, x_ext):
+                        ops.rmsnorm_fwd(h, L["ln1"], self.eps, out=x_ext[:, :D])
+                        self.lora.forward_border(li, x_ext, training=False)
+                    qkv = ops.gemv_packed(x_ext, P["wqkv"])
+                else:
+                    qkv = ops.gemv_packed_rmsnorm(h, L["ln1"], self.eps, P["wqkv"])
+                    if qkv is None:
+                        qkv = ops.gemv_packed(ops.rmsnorm_fwd(h, L["ln1"], self.eps), P["wqkv"])
                 o = ops.attn_decode_rope(qkv, cache, pos, pos_dev, kvlen_dev, self.cos, self.sin, H, hd, scale)
                 h2 = ops.gemv_packed(o, P["wo"], residual=h, out_dtype=F32)
                 gu = ops.gemv_packed_rmsnorm(h2, L["ln2"], self.eps, P["wgu"])

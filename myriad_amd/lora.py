@@ -132,6 +132,17 @@ class LoraQV:
                                             x_ext.stride(0), M, D, 2 * r, self.s, p, seed, ops._s()), "mh_lora_down")
         return p, seed
 
+    def norm_border(self, layer_idx: int, h: torch.Tensor, norm_w: torch.Tensor, eps: float, x_ext: torch.Tensor) -> bool:
+        """Single-token decode (<= 2 rows, no dropout): x_ext <- [bf16(rmsnorm(h)) | border] in ONE launch, the bits of
+        ops.rmsnorm_fwd(out=x_ext[:, :D]) + forward_border(training=False).  False: not supported for this shape, nothing written."""
+        rc = _lib.load().mh_rmsnorm_lora_down(h.data_ptr(), h.stride(0), norm_w.data_ptr(), float(eps),
+                                              self._aqv(self.P, layer_idx).data_ptr(), x_ext.data_ptr(), x_ext.stride(0), h.shape[0],
+                                              self.D, 2 * self.r, self.s, ops._s())
+        if rc == -3:                                   # MH_ERR_UNSUPPORTED
+            return False
+        _lib.check(rc, "mh_rmsnorm_lora_down")
+        return True
+
     # ---- backward ------------------------------------------------------------------------------------------------
     def backward(self, layer_idx: int, dx_ext: torch.Tensor, dqkv: torch.Tensor, x_ext: torch.Tensor, p: float,
                  seed: int, defer_wgrad: bool = False) -> torch.Tensor:

@@ -201,6 +201,30 @@ def test_graph_replayed_decode_equals_eager_decode(model):
         model.train()
 
 
+def test_decode_with_lora_attached_fused_step_equals_the_separate_launches(model):
+    """The model that generates is the fine-tuned one: LoRA on q_proj / v_proj stays attached (unmerged, as peft leaves it).  Its
+    single-token step runs the fused launches too -- norm + LoRA down projection as one launch in front of the bordered packed qkv
+    weight, rotary + append inside the attention, norm / SiLU gate inside the MLP products -- and must give exactly the tokens of
+    the launch-per-op path (MYRIAD_DECODE_FUSED=0), at batch 1 (every fusion active) and batch 3 (the <= 2-row ones fall back)."""
+    model.eval()
+    llm = model.llama
+    assert llm.lora is not None
+    try:
+        kw = dict(max_new_tokens=10, stop_ids=((-1,),), min_length=0, eos_token_id=-5)
+        for B in (1, 3):
+            s = {k: v for k, v in samples(B, seed=31 + B).items() if k not in ("target_ids", "target_mask")}
+            outs = []
+            for fused in (True, False):
+                llm.decode_fused = fused
+                llm._decode_ws.clear()
+                outs.append(model.generate(s, **kw)["token_ids"])
+            assert outs[0].shape == (B, 10) and torch.equal(outs[0], outs[1])
+    finally:
+        llm.decode_fused = True
+        llm._decode_ws.clear()
+        model.train()
+
+
 def test_decode_graph_and_buffers_survive_across_generate_calls(model):
     """The token-step graph, KV caches and device counters are kept per batch size and re-used by later generate() calls:
     interleaved calls with different prompts, lengths and batch sizes must give exactly the tokens a fresh state gives."""

@@ -580,6 +580,33 @@ def test_lora_backward_fused_with_the_qkv_dgrad_is_bit_identical():
     assert torch.equal(outs[0][1], outs[1][1]) and float(outs[0][1].abs().sum()) > 0
 
 
+@pytest.mark.parametrize("M", [1, 2, 3])
+def test_decode_norm_and_lora_down_in_one_launch_are_bit_identical(M):
+    """mh_rmsnorm_lora_down (LoraQV.norm_border): the RMSNorm of <= 2 residual rows and their LoRA border in one launch -- every
+    workgroup rebuilds the rows in rmsnorm_fwd_kernel's order -- against mh_rmsnorm_fwd + mh_lora_down: same x_ext, bit for bit;
+    three rows are refused (the caller runs the two launches)."""
+    from myriad_amd.lora import BORDER, LoraQV, lora_param_specs
+    from myriad_amd.myriad import ParamStore
+    D, r = 4096, 8
+    st = ParamStore(lora_param_specs(1, D, r), DEV)
+    g2 = torch.Generator().manual_seed(91)
+    for name, ishape, _ in st.specs:
+        st.p[name].copy_(torch.randn(ishape, generator=g2) * 0.05)
+    lora = LoraQV(1, D, r, 16.0, 0.05, st.p, st.g, DEV)
+    h = (torch.randn(M, D, generator=g2) * 1.3).to(DEV)
+    w = (1 + 0.1 * torch.randn(D, generator=g2)).to(DEV)
+    want = torch.zeros(M, D + BORDER, dtype=torch.bfloat16, device=DEV)
+    ops.rmsnorm_fwd(h, w, 1e-6, out=want[:, :D])
+    lora.forward_border(0, want, training=False)
+    got = torch.full((M, D + BORDER), 7.0, dtype=torch.bfloat16, device=DEV)
+    ok = lora.norm_border(0, h, w, 1e-6, got)
+    torch.cuda.synchronize()
+    if M > 2:
+        assert not ok and float((got - 7.0).abs().max()) == 0
+        return
+    assert ok and torch.equal(got, want) and float(want[:, D:].float().abs().sum()) > 0
+
+
 @pytest.mark.parametrize("M,p", [(1184, 0.05), (1184, 0.0), (148, 0.05), (37, 0.05), (5, 0.05)])
 def test_lora_weight_gradients_as_mfma_products(M, p):
     """mh_lora_wgrad's MFMA kernel (option lora_wgrad_mfma, the default at r = 8) against the thread-per-column kernel it replaces

@@ -11,10 +11,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=1)
 ap.add_argument("--new", type=int, default=32)
 ap.add_argument("--llm-layers", type=int, default=32)
+ap.add_argument("--lora", type=int, default=0, help="1: PEFT LoRA r = 8 on q_proj / v_proj attached (the fine-tuned model's generate)")
 a = ap.parse_args()
 dev = "cuda:0"
 cfg = full_config(llm_layers=a.llm_layers)
-model = MyriadHIP(SyntheticWeights(cfg, dev, seed=0), dict(need_backward=False), device=dev)
+model = MyriadHIP(SyntheticWeights(cfg, dev, seed=0), dict(need_backward=False, use_lora=bool(a.lora)), device=dev)
 model.eval()
 g = torch.Generator().manual_seed(1)
 B = a.batch
@@ -34,5 +35,5 @@ t_short, _ = run(a.new // 4)
 t_long, out = run(a.new)
 n_long, n_short = out["token_ids"].shape[1], a.new // 4
 per_tok = (t_long - t_short) / (n_long - n_short)    # prefill / vision cancel: pure single-token decode steps
-print(f"batch {B}: {n_long} tokens in {t_long*1e3:.1f} ms (incl. ViT+Q-Former+prefill); decode step {per_tok*1e3:.2f} ms/token "
+print(f"batch {B}{' +LoRA' if a.lora else ''}: {n_long} tokens in {t_long*1e3:.1f} ms (incl. ViT+Q-Former+prefill); decode step {per_tok*1e3:.2f} ms/token "
       f"-> {B / per_tok:.1f} tok/s steady; weight stream {13.2e9 / per_tok / 1e12:.2f} TB/s of 6.3 achievable")

@@ -414,6 +414,8 @@ int mh_target_arch(void); /* 950 */
  *                       K and V of a (batch, head) (attn_full.hip) instead of 64x64 tiles; 0 = the tiled kernel
  *   lora_wgrad_mfma (1) mh_lora_wgrad at r = 8, D % 128 == 0: the sums over token rows as MFMA products (per-row scalars as a bf16 head +
  *                       bf16 remainder, fp32 accumulation); 0 = the thread-per-column fp32 kernel
+ *   gemm_skip_pad (1)   256x256 kernel: a wave whose rows lie past M but for at most two 16-row fragments issues no MFMAs for the others
+ *                       (same results; the chip's clock under this loop is set by the matrix pipes' power); 0 = every wave runs the full loop
  * mh_set_option returns the previous value (0 / 1) or MH_ERR_ARG (unknown name, value not 0 / 1); mh_get_option the current
  * value or MH_ERR_ARG.  Not thread-safe against concurrent launches. */
 int mh_set_option(const char* name, int value);

@@ -32,6 +32,7 @@
 #define X4_F_SAME_PANEL 0x40000000   // every workgroup stages tile (0, 0)'s panels (all-L2-hit timing probe; sweep builds)
 #define X4_F_ZERO_PAD 0x20000000     // rows past M / N read as zeros (default on; option gemm_zero_pad)
 #define X4_F_CLOCK_PROBE 0x10000000  // aux = int64 stamps of workgroups 0, 64, .. (mhdbg_set_gemm_x4_clock_probe)
+#define X4_F_SKIP_PAD 0x04000000     // waves whose rows lie (almost) all past M skip those fragments' MFMAs (option gemm_skip_pad)
 #define X4_F_NO_STORES 0x08000000    // read-out without its global stores (mhdbg_set_gemm_x4_no_stores: timing only, wrong results)
 #define MH_GEMM_SWIGLU_FWD 16
 #define MH_GEMM_SWIGLU_BWD 32
@@ -502,6 +503,14 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__
     sb[3] = 0x00020000;
     unsigned koff = (unsigned)kt0 * 128u, cnt = (unsigned)nt, wr = sbase + wave * 1024;
     if (probe) pr1 = (long long)__builtin_amdgcn_s_memrealtime();
+    // This wave's 128-row slab reaches at most two fragments (32 rows) below M -- the second wave row of the last row tile of the
+    // M = 1184 launches (160 of 256 rows), both wave rows of the ViT's (8 of 256): it runs the loop WITHOUT the MFMAs of fragments
+    // 2..7 (gen_gemm_x4.py: `ni_act`), whose accumulators are never stored.  Same requests, reads, waits and barriers, same
+    // results; 7 % of those launches' MFMA issues are not made at all on a chip whose clock is set by the matrix pipes' power.
+    // A wave with no row below M or no column below N (the 17th column tile of the N = 4160 / 4224 launches has 64 / 128 of its
+    // 256 columns) issues none.
+    const int rows_left = M - (m0 + wm * 128), cols_left = N - (n0 + wn * 64);
+    const int x8_part = !(flags & X4_F_SKIP_PAD) ? 0 : ((rows_left <= 0 || cols_left <= 0) ? 2 : (rows_left <= 32 ? 1 : 0));
     X4_DISPATCH8(V);
     if (probe) pr2 = (long long)__builtin_amdgcn_s_memrealtime();
   }
@@ -562,6 +571,7 @@ int mh_launch_gemm_x4(const void* A, int lda, const void* B, int ldb, void* C, i
   const dim3 grid(tiles_m * tiles_n, splits);
   if (x4_same_panel) flags |= X4_F_SAME_PANEL;
   if (mh_opt(MH_OPT_GEMM_ZERO_PAD)) flags |= X4_F_ZERO_PAD;
+  if (mh_opt(MH_OPT_GEMM_SKIP_PAD)) flags |= X4_F_SKIP_PAD;
   if (x4_no_stores) flags |= X4_F_NO_STORES;
   if (x4_clock_probe && !aux && !(flags & (MH_GEMM_SWIGLU_FWD | MH_GEMM_SWIGLU_BWD))) { flags |= X4_F_CLOCK_PROBE; aux = x4_clock_probe; }
   if (g_mh_prof_on) mh_prof_pre(stream, 2, M, N, K, splits, flags);

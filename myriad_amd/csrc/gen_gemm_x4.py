@@ -103,8 +103,11 @@ def dma_requests(waves=4):
     return out
 
 
-def body(kind, V):
-    """kind: 'steady' (requests k-tile t+2, reads t+1), 'tail2' (no requests, reads t+1), 'last' (neither)."""
+def body(kind, V, ni_act=8):
+    """kind: 'steady' (requests k-tile t+2, reads t+1), 'tail2' (no requests, reads t+1), 'last' (neither).
+    ni_act < 8: the body of a wave whose A fragments ni_act.. are rows past M -- their MFMAs become `s_nop 0` (one issue cycle each,
+    so every hazard spacing of the full body survives) while the reads, requests, waits and barriers stay where they are: the wave
+    keeps step with the full-body waves of its workgroup and multiplies nothing that is never stored."""
     rd, dma, mid, end, fine, ko = V["rd"], V["dma"], V["mid"], V["end"], V["fine"], V["ko"].split()
     waves = V["waves"]
     nj = 8 if waves == 4 else 4                             # B fragments per wave
@@ -158,7 +161,7 @@ def body(kind, V):
                         q = (slot // 2) % 16
                         L.append(f"v_mfma_f32_32x32x16_bf16 a[{q * 16}:{q * 16 + 15}], {vreg(bb, j)}, {vreg(ab, i)}, a[{q * 16}:{q * 16 + 15}]")
                 elif "mfma" not in ko:
-                    L.append(mfma(i, j, ab, bb, nj))
+                    L.append(mfma(i, j, ab, bb, nj) if i < ni_act else "s_nop 0")
                 L += extras[slot]
                 slot += 1
     if kind != "last":
@@ -169,7 +172,7 @@ def body(kind, V):
     return L
 
 
-def program(V):
+def program(V, ni_act=8):
     waves = V["waves"]
     nj = 8 if waves == 4 else 4
     nacc = 8 * nj * 4
@@ -200,15 +203,15 @@ def program(V):
     P.append("X4_LOOP_%=:")
     P.append("s_cmp_le_u32 s45, 2")
     P.append("s_cbranch_scc1 X4_TAIL_%=")
-    P += body("steady", V)
+    P += body("steady", V, ni_act)
     P.append("s_sub_u32 s45, s45, 1")
     P.append("s_branch X4_LOOP_%=")
     P.append("X4_TAIL_%=:")
     P.append("s_cmp_eq_u32 s45, 1")
     P.append("s_cbranch_scc1 X4_LAST_%=")
-    P += body("tail2", V)
+    P += body("tail2", V, ni_act)
     P.append("X4_LAST_%=:")
-    P += body("last", V)
+    P += body("last", V, ni_act)
     P.append("s_waitcnt vmcnt(0) lgkmcnt(0)")               # (knock-out variants may leave something in flight)
     P.append("s_nop 7")
     P.append("s_nop 7")
@@ -240,10 +243,24 @@ def main():
                 f.write('  "' + ln + '\\n\\t" \\\n')
             f.write('  ""\n')
             n_mfma = sum(1 for l in lines if l.startswith("v_mfma"))
+            if vi == 0 and V["waves"] == 8:
+                # the shipped loop once more for waves that own at most two row fragments below M (gemm_x4.hip: `x8_part`)
+                # ... and for waves with nothing below M / N at all
+                for na in (2, 0):
+                    f.write(f"#define X4_LOOP_{vi}_P{na} \\\n")
+                    for ln in program(V, na):
+                        f.write('  "' + ln + '\\n\\t" \\\n')
+                    f.write('  ""\n')
             if vi == len(variants) - 1:
                 for w, asm in ((4, "X4_ASM"), (8, "X8_ASM")):
                     idx = [i for i, v in enumerate(variants) if v["waves"] == w]
-                    chain = " else ".join(f"if constexpr (V == {i}) {{ {asm}(X4_LOOP_{i}); }}" for i in idx) or "(void)0"
+
+                    def use(i):
+                        if w == 8 and i == 0:
+                            return (f"if (x8_part == 2) {{ {asm}(X4_LOOP_0_P0); }} else if (x8_part == 1) {{ {asm}(X4_LOOP_0_P2); }} "
+                                    f"else {{ {asm}(X4_LOOP_0); }}")
+                        return f"{asm}(X4_LOOP_{i});"
+                    chain = " else ".join(f"if constexpr (V == {i}) {{ {use(i)} }}" for i in idx) or "(void)0"
                     f.write(f"#define X4_DISPATCH{w}(V) {chain}\n")
                 cases = " ".join(f"case {i}: X{v['waves']}_LAUNCH({i}) break;" for i, v in enumerate(variants))
                 f.write(f"#define X4_LAUNCH_SWITCH {cases}\n")

@@ -236,6 +236,32 @@ def test_padding_rows_of_the_256_tile_read_zeros_and_change_nothing(M, N, K, pad
     assert not torch.isnan(outs[0][1]).any()
 
 
+@pytest.mark.parametrize("M,N,K", [(1184, 4096, 4096), (1184, 22016, 4096), (2056, 4224, 1408), (1056, 512, 384), (1057, 512, 128),
+                                   (160, 256, 64), (257, 256, 192), (1184, 4160, 12288), (300, 328, 192)])
+def test_waves_past_the_last_row_skip_their_matrix_instructions_and_change_nothing(M, N, K):
+    """256 x 256 kernel: a wave whose 128-row slab has at most two 16-row fragments below M (the second wave row of the LLaMA
+    launches' fifth row tile, both wave rows of the ViT's ninth) runs the generated loop without the MFMAs of its other six
+    fragments, a wave with no row below M or no column below N (N = 4160, 4224, 328) without any (option gemm_skip_pad;
+    gen_gemm_x4.py ni_act).  Same requests / waits / barriers, so the SAME bits as the full loop:
+    bf16 and f32 outputs with bias, K split and unsplit, one / two / three k-tiles (all three loop bodies), M that leaves exactly 32,
+    33 (no skipping), 160 and 1 rows in the last tile."""
+    hook = _opt_hook("gemm_skip_pad")
+    ops.ensure_workspace(torch.device(DEV))
+    a = bf(rnd(M, K, seed=241)).to(DEV)
+    b = bf(rnd(N, K, seed=242) * 0.05).to(DEV)
+    bias = rnd(N, seed=243).to(DEV)
+    outs = []
+    try:
+        for on in (1, 0):
+            hook(on)
+            outs.append((ops.gemm(a, b, bias=bias, variant=12), ops.gemm(a, b, out_dtype=torch.float32, variant=12)))
+    finally:
+        hook(1)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert relerr(outs[0][1], a.float() @ b.float().T) < 6e-3
+    assert not torch.isnan(outs[0][1]).any()
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 12288, 4160), (16, 1000, 11008), (3, 32000, 4096)])
 def test_skinny_m_weight_streaming_gemm(M, N, K):
     """M <= 16 routes to the decode weight-streaming kernel (gemv.hip)."""

@@ -38,12 +38,15 @@ BREG = 0x8000     # offset of the B region inside a buffer
 #   fine    1: the loop edge waits only for the fragments the first MFMA row needs (lgkmcnt(7)); row i of the next
 #           iteration waits for its own A fragment with a counted lgkmcnt
 #   ko      timing-only knock-outs (WRONG results): "dma", "rd", "bar", "mfma" in any combination
+#   order   "snake": the B fragments of odd A rows are walked backwards, so consecutive MFMAs always share one operand (row changes
+#           keep B, column changes keep A); "": every row walks B 0..nj-1.  Same sums per accumulator; on a chip whose clock under this
+#           loop is set by the matrix pipes' power the operand that does not change is worth 0.6 % of the step (r05_experiments.md)
 #   waves   4: 2 x 2 waves, 128 x 128 per wave, one wave per SIMD (256 accumulators, 128 MFMA slots per iteration)
 #           8: 2 x 4 waves, 128 x 64 per wave, two waves per SIMD (128 accumulators, 64 MFMA slots per iteration per wave; each
 #              wave issues half the requests: 4 + 4, m0 stride 8192) -- what one wave cannot hide under its own MFMAs (the issue
 #              time of its LDS-DMA requests and fragment reads) the SIMD's other wave fills
 X4 = dict(waves=4, rd=2, dma=3, mid=36, end=96, fine=1, ko="")
-X8 = dict(waves=8, rd=1, dma=4, mid=14, end=50, fine=1, ko="")
+X8 = dict(waves=8, rd=1, dma=4, mid=14, end=50, fine=1, ko="", order=os.environ.get("X8_ORDER", "snake"))
 DEFAULT = X8        # shipped: tools/gemm_x4_sweep.py, profiles/r04_gemm_x4.md
 SWEEP = [
     dict(X8),
@@ -154,7 +157,7 @@ def body(kind, V, ni_act=8):
     slot = 0
     for ab, bb in ((g["A0"], g["B0"]), (g["A1"], g["B1"])):
         for i in range(8):
-            for j in range(nj):
+            for j in (range(nj) if (i % 2 == 0 or "snake" not in V.get("order", "")) else reversed(range(nj))):
                 if "mfma32" in ko:
                     # timing probe: the same FLOPs as 32x32x16 instructions (half as many, twice as long); wrong results
                     if slot % 2 == 0:

@@ -354,7 +354,18 @@ __global__ void splitk_reduce_kernel(const void* __restrict__ ws, void* __restri
   for (long i4 = blockIdx.x * (long)blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
     const long i = i4 * 4;
     float4_t s = slab_load4(ws, i, sbf);
-    for (int k = 1; k < splits; ++k) {
+    // slabs in ascending order, eight loads in flight at a time: a wgrad with a long reduction has up to 196 slabs of a tiny output,
+    // and one load latency per slab made that launch 100+ us (the batch-1 step's 7-11 slabs: 6 -> 4 us)
+    int k = 1;
+    if (splits > 4)
+    for (; k + 8 <= splits; k += 8) {
+      float4_t p[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) p[u] = slab_load4(ws, (long)(k + u) * slab + i, sbf);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s[0] += p[u][0]; s[1] += p[u][1]; s[2] += p[u][2]; s[3] += p[u][3]; }
+    }
+    for (; k < splits; ++k) {
       const float4_t p = slab_load4(ws, (long)k * slab + i, sbf);
       s[0] += p[0]; s[1] += p[1]; s[2] += p[2]; s[3] += p[3];
     }
@@ -404,7 +415,16 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const void* __r
   int c = 0;
   for (int i = threadIdx.x * 4; i < N; i += 1024, ++c) {
     float4_t sacc = slab_load4(ws, row * N + i, sbf);
-    for (int k = 1; k < splits; ++k) {
+    int k = 1;
+    if (splits > 4)                                 // (the batch-8 step's 3-slab launches keep the plain loop: measured faster)
+    for (; k + 4 <= splits; k += 4) {               // ascending order, four loads in flight (the batch-1 step's 8-11 slabs)
+      float4_t p[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p[u] = slab_load4(ws, (long)(k + u) * slab + row * N + i, sbf);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { sacc[0] += p[u][0]; sacc[1] += p[u][1]; sacc[2] += p[u][2]; sacc[3] += p[u][3]; }
+    }
+    for (; k < splits; ++k) {
       const float4_t p = slab_load4(ws, (long)k * slab + row * N + i, sbf);
       sacc[0] += p[0]; sacc[1] += p[1]; sacc[2] += p[2]; sacc[3] += p[3];
     }

@@ -651,16 +651,26 @@ __global__ void lora_wgrad_reduce_kernel(const float* __restrict__ pA, const flo
                                          const float* __restrict__ pBv, float* __restrict__ dA, float* __restrict__ dBq,
                                          float* __restrict__ dBv, int nA, int nB, int nch) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  // chunks in ascending order, eight loads in flight at a time (nch is 16 or 64)
   if (i < nA) {
     float s = 0.f;
-    for (int c = 0; c < nch; ++c) s += pA[(long)c * nA + i];
+    for (int c = 0; c < nch; c += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = pA[(long)(c + u) * nA + i];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
     dA[i] = s;
   }
   if (i < nB) {
     float s = 0.f, t = 0.f;
-    for (int c = 0; c < nch; ++c) {
-      s += pBq[(long)c * nB + i];
-      t += pBv[(long)c * nB + i];
+    for (int c = 0; c < nch; c += 8) {
+      float v[8], x[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { v[u] = pBq[(long)(c + u) * nB + i]; x[u] = pBv[(long)(c + u) * nB + i]; }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) { s += v[u]; t += x[u]; }
     }
     dBq[i] = s;
     dBv[i] = t;

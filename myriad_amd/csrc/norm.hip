@@ -50,7 +50,16 @@ __global__ __launch_bounds__(NT) void rmsnorm_bwd_kernel(const void* __restrict_
   for (int i = threadIdx.x * 4; i < D; i += NT * 4, ++c) {
     const float4_t v = *reinterpret_cast<const float4_t*>(xr + i);
     float4_t g = slab_load4(dy, g0 + i, sbf);
-    for (int k = 1; k < nslab; ++k) {
+    int k = 1;
+    if (nslab > 4)                                   // (the batch-8 step's 3-slab launches keep the plain loop: measured faster)
+    for (; k + 4 <= nslab; k += 4) {                 // ascending order, four loads in flight (the batch-1 step's 8 slabs)
+      float4_t p[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) p[u] = slab_load4(dy, g0 + (long)(k + u) * slab + i, sbf);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { g[0] += p[u][0]; g[1] += p[u][1]; g[2] += p[u][2]; g[3] += p[u][3]; }
+    }
+    for (; k < nslab; ++k) {
       const float4_t p = slab_load4(dy, g0 + (long)k * slab + i, sbf);
       g[0] += p[0]; g[1] += p[1]; g[2] += p[2]; g[3] += p[3];
     }

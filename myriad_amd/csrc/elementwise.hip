@@ -81,8 +81,11 @@ __global__ void silu_mul_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __res
   }
 }
 
+// nslab > 0: dh is not a bf16 matrix but the split-K partial slabs [nslab][M][I] (fp32, or bf16 when sbf) of the down projection's
+// dgrad (mh_gemm_swiglu_bwd at the batch-1 step): summed here in slab order and rounded to bf16 as splitk_reduce_kernel does, so
+// the same bits as GEMM -> reduce -> this kernel with one launch and one round trip of dact less.
 __global__ void silu_mul_bwd_kernel(const bf16_t* __restrict__ dh, const bf16_t* __restrict__ gu,
-                                    bf16_t* __restrict__ dgu, long M, int I, int blk) {
+                                    bf16_t* __restrict__ dgu, long M, int I, int blk, int nslab = 0, long slab = 0, int sbf = 0) {
   const int per_row = I >> 3;
   const long total = M * per_row;
   for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
@@ -92,7 +95,23 @@ __global__ void silu_mul_bwd_kernel(const bf16_t* __restrict__ dh, const bf16_t*
     const long gc = silu_gcol(c, I, blk, &us);
     const short8_t g = *reinterpret_cast<const short8_t*>(gu + m * 2 * I + gc);
     const short8_t u = *reinterpret_cast<const short8_t*>(gu + m * 2 * I + gc + us);
-    const short8_t d = *reinterpret_cast<const short8_t*>(dh + m * I + c);
+    short8_t d;
+    if (nslab > 0) {
+      const void* ws = dh;
+      float4_t s0 = slab_load4(ws, m * I + c, sbf), s1 = slab_load4(ws, m * I + c + 4, sbf);
+      for (int k = 1; k < nslab; ++k) {
+        const float4_t p0 = slab_load4(ws, (long)k * slab + m * I + c, sbf), p1 = slab_load4(ws, (long)k * slab + m * I + c + 4, sbf);
+        s0[0] += p0[0]; s0[1] += p0[1]; s0[2] += p0[2]; s0[3] += p0[3];
+        s1[0] += p1[0]; s1[1] += p1[1]; s1[2] += p1[2]; s1[3] += p1[3];
+      }
+      // splitk_reduce_kernel: v = s * alpha (alpha = 1), then the packed bf16 conversion
+      const unsigned q0 = pack_bf2(s0[0] * 1.0f, s0[1] * 1.0f), q1 = pack_bf2(s0[2] * 1.0f, s0[3] * 1.0f);
+      const unsigned q2 = pack_bf2(s1[0] * 1.0f, s1[1] * 1.0f), q3 = pack_bf2(s1[2] * 1.0f, s1[3] * 1.0f);
+      d = (short8_t){(short)(q0 & 0xffffu), (short)(q0 >> 16), (short)(q1 & 0xffffu), (short)(q1 >> 16),
+                     (short)(q2 & 0xffffu), (short)(q2 >> 16), (short)(q3 & 0xffffu), (short)(q3 >> 16)};
+    } else {
+      d = *reinterpret_cast<const short8_t*>(dh + m * I + c);
+    }
     short8_t og, ou;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -120,6 +139,16 @@ extern "C" int mh_silu_mul_bwd_blk(const void* dh, const void* gu, void* dgu, in
   if (I % 8 || blk < 0 || (blk && ((blk % 8) || (I % blk)))) return MH_ERR_ARG;
   hipLaunchKernelGGL(silu_mul_bwd_kernel, dim3(ew_grid((long)M * (I / 8))), dim3(EW_NT), 0, stream,
                      (const bf16_t*)dh, (const bf16_t*)gu, (bf16_t*)dgu, (long)M, I, blk);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+// dh as split-K slabs (gemm.hip mh_gemm_swiglu_bwd)
+int mh_launch_silu_mul_bwd_slabs(const void* ws, int slab_bf16, int nslab, long slab, const void* gu, void* dgu, int M, int I, int blk,
+                                 hipStream_t stream) {
+  if (M <= 0) return MH_OK;
+  if (I % 8 || blk < 0 || (blk && ((blk % 8) || (I % blk))) || nslab < 1) return MH_ERR_ARG;
+  hipLaunchKernelGGL(silu_mul_bwd_kernel, dim3(ew_grid((long)M * (I / 8))), dim3(EW_NT), 0, stream, (const bf16_t*)ws,
+                     (const bf16_t*)gu, (bf16_t*)dgu, (long)M, I, blk, nslab, slab, slab_bf16);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

@@ -945,6 +945,8 @@ extern "C" int mh_gemm_attn_rope_bwd(const void* A, int lda, const void* Bw, int
 #define MH_GEMM_SWIGLU_BWD 32
 extern "C" int mh_silu_mul_fwd_blk(const void* gu, void* h, int M, int I, int blk, hipStream_t stream);
 extern "C" int mh_silu_mul_bwd_blk(const void* dh, const void* gu, void* dgu, int M, int I, int blk, hipStream_t stream);
+int mh_launch_silu_mul_bwd_slabs(const void* ws, int slab_bf16, int nslab, long slab, const void* gu, void* dgu, int M, int I, int blk,
+                                 hipStream_t stream);
 
 
 static bool swiglu_fusable(int M, int N, int K, int lda, int ldb, const void* A, const void* B) {
@@ -982,6 +984,25 @@ extern "C" int mh_gemm_swiglu_bwd(const void* dH, int lddh, const void* WdT, int
     return mh_launch_gemm_256(dH, lddh, WdT, ldw, dgu, lddgu, M, I, K, nullptr, nullptr, 0, MH_GEMM_SWIGLU_BWD, 1.0f, 1, K / 64,
                               0L, stream, const_cast<void*>(gu), ldgu);
   if (!dact_buf || ldgu != 2 * I || lddgu != 2 * I) return MH_ERR_ARG;
+  {
+    // K-split product (the batch-1 step's 160-row tiles): the gate backward sums the slabs itself -- no reduce launch, same bits
+    int kernel = 1, splits = 1;
+    gemm_plan(M, I, K, 0, &kernel, &splits);
+    if (splits > 1 && kernel != 0 && (I % 8) == 0 && (K % 64) == 0 && (lddh % 8) == 0 && (ldw % 8) == 0 &&
+        !(((uintptr_t)dH | (uintptr_t)WdT) & 15)) {
+      GemmArgs g = {dH, lddh, WdT, ldw, dact_buf, I, M, I, K, nullptr, nullptr, 0, 0, 1.0f, 1, K / 64, 0L};
+      g.flags |= plan_variant(kernel) << MH_GEMM_VARIANT_SHIFT;
+      const int nt = K / 64;
+      int sp = splits > nt ? nt : splits;
+      const int tps = (nt + sp - 1) / sp;
+      sp = (nt + tps - 1) / tps;
+      float* wsp = ws_for(stream);
+      int sbf = 0;
+      const int rc = run_splitk(g, splits, wsp, stream, /*reduce=*/false, &sbf);
+      if (rc) return rc;
+      return mh_launch_silu_mul_bwd_slabs(wsp, sbf, sp, (long)M * I, gu, dgu, M, I, 128, stream);
+    }
+  }
   const int rc = mh_gemm_bf16_nt(dH, lddh, WdT, ldw, dact_buf, I, M, I, K, nullptr, nullptr, 0, 0, 1.0f, stream);
   if (rc) return rc;
   return mh_silu_mul_bwd_blk(dact_buf, gu, dgu, M, I, 128, stream);

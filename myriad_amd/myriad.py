@@ -587,7 +587,11 @@ class MyriadHIP(nn.Module):
         if c is None:
             raise RuntimeError("backward() without a training forward")
         prev = self.store.flat_g_comm.clone() if accumulate else None
-        self.store.flat_g_comm.zero_()
+        zeroed, self._g_zeroed = getattr(self, "_g_zeroed", None), None
+        if zeroed is not None and not accumulate:
+            torch.cuda.current_stream().wait_event(zeroed)        # train_step filled it on the leaf stream during the forward
+        else:
+            self.store.flat_g_comm.zero_()
         used = {"lora"} if self.use_lora else set()
         if self.arch == "myriad":
             used.add("expert_adaptor")
@@ -829,6 +833,15 @@ class MyriadHIP(nn.Module):
                 # frozen ViT forward (independent of the update) under it, then apply the delayed AdamW.
                 vit_out = self.visual_encoder.forward(self._image_of(samples))
                 self.finish_update()
+            if self._accum_count == 0 and self._leaf_aside and os.environ.get("MYRIAD_EARLY_ZERO", "1") != "0":
+                # the gradient buffer's zero fill (460 MB, ~55 us) leaves the chain between forward and backward: nothing writes a
+                # gradient before the backward, and the last update (main stream, and the leaf stream itself) has read them
+                aux, main = self._side_stream("leaf"), torch.cuda.current_stream()
+                aux.wait_stream(main)
+                with torch.cuda.stream(aux):
+                    self.store.flat_g_comm.zero_()
+                    self._g_zeroed = torch.cuda.Event()
+                    self._g_zeroed.record(aux)
             loss = self._forward_impl(samples, True, vit_out=vit_out)
             accumulate = self._accum_count > 0                   # > 0: the flat buffer holds gradients no update has consumed
             due = accum_update_due(self._accum_count + 1, accum_grad_iters, accum_index)

@@ -416,6 +416,9 @@ int mh_target_arch(void); /* 950 */
  *                       bf16 remainder, fp32 accumulation); 0 = the thread-per-column fp32 kernel
  *   gemm_skip_pad (1)   256x256 kernel: a wave whose rows lie past M but for at most two 16-row fragments issues no MFMAs for the others
  *                       (same results; the chip's clock under this loop is set by the matrix pipes' power); 0 = every wave runs the full loop
+ *   gemm_split_xcd (1)  256x256 kernel, K-split launches: the workgroups of one XCD (round-robin dispatch, private L2) own ONE K split of a
+ *                       band of tile columns, so each L2 streams its A panels' K range once; 0 = every XCD runs all splits of a tile
+ *                       block and reads the whole A matrix (same results, the mapping only moves workgroups)
  * mh_set_option returns the previous value (0 / 1) or MH_ERR_ARG (unknown name, value not 0 / 1); mh_get_option the current
  * value or MH_ERR_ARG.  Not thread-safe against concurrent launches. */
 int mh_set_option(const char* name, int value);

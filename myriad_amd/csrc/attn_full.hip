@@ -198,7 +198,7 @@ int mh_launch_attn_full_fwd(const void* q, const void* k, const void* v, void* o
                             hipStream_t stream) {
   if (D % 8 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || Sk > 288 || Sq <= 0 || Sk <= 0) return MH_ERR_UNSUPPORTED;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) & 15 || ((uintptr_t)o & 7)) return MH_ERR_UNSUPPORTED;
-  if ((D * 2) % 16 || (q_bs % 8) || (k_bs % 8) || (v_bs % 8)) return MH_ERR_UNSUPPORTED;   // 16-byte row chunks of every head
+  if ((D * 2) % 16 || (q_bs % 8) || (k_bs % 8) || (v_bs % 8) || (o_bs % 4)) return MH_ERR_UNSUPPORTED;   // 16-byte row chunks of every head; O is stored as 8-byte words
   AttnFullParams p = {(const bf16_t*)q, (const bf16_t*)k, (const bf16_t*)v, (bf16_t*)o, lse, q_bs, k_bs, v_bs, o_bs,
                       ldq, ldk, ldv, ldo, B, H, Sq, Sk, D, scale, 0};
   if (D > 64 && D <= 96) return af_launch<96, 288>(p, stream);

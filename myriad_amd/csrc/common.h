@@ -45,6 +45,7 @@ enum MhOpt {
   MH_OPT_ATTN_FULL,         // whole-sequence forward attention (attn_full.hip) for unmasked Sk <= 288, head dim <= 96
   MH_OPT_LORA_WGRAD_MFMA,   // LoRA weight gradients as MFMA products (r = 8, D % 128 == 0); 0: the thread-per-column kernel
   MH_OPT_GEMM_SKIP_PAD,     // 256x256 kernel: waves whose rows lie past M (but for <= 2 fragments) issue no MFMAs for them
+  MH_OPT_GEMM_SPLIT_XCD,    // 256x256 kernel, K-split launches: an XCD owns one split of a band of tile columns (0: all splits of a tile block)
   MH_OPT_COUNT
 };
 int mh_opt(int id);

@@ -33,6 +33,7 @@
 #define X4_F_ZERO_PAD 0x20000000     // rows past M / N read as zeros (default on; option gemm_zero_pad)
 #define X4_F_CLOCK_PROBE 0x10000000  // aux = int64 stamps of workgroups 0, 64, .. (mhdbg_set_gemm_x4_clock_probe)
 #define X4_F_SKIP_PAD 0x04000000     // waves whose rows lie (almost) all past M skip those fragments' MFMAs (option gemm_skip_pad)
+#define X4_F_SPLIT_XCD 0x02000000    // K-split launches: an XCD owns one split of a band of tile columns (option gemm_split_xcd)
 #define X4_F_NO_STORES 0x08000000    // read-out without its global stores (mhdbg_set_gemm_x4_no_stores: timing only, wrong results)
 #define MH_GEMM_SWIGLU_FWD 16
 #define MH_GEMM_SWIGLU_BWD 32
@@ -444,9 +445,24 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__
   if (probe) { pc0 = (long long)__builtin_amdgcn_s_memtime(); pr0 = (long long)__builtin_amdgcn_s_memrealtime(); }
   const int lr = lane & 15, lg = lane >> 4;
 
-  const int nwg = gridDim.x, bid = blockIdx.x;
+  // Which (tile, K split) this workgroup owns.  Workgroups are handed to the eight XCDs round-robin in launch order (x fastest,
+  // then y), each XCD has its own L2.  Unsplit launches: an XCD's workgroups are one contiguous run of the grouped tile order
+  // (below).  K-split launches (round 6, option gemm_split_xcd): the run is taken from the list ordered (split, tile column,
+  // tile row), so an XCD works on ONE split (two at a seam) of a band of tile columns -- it streams the A panel of that K range
+  // once and each of its B panels once.  Before, every XCD ran all splits of a 5 x 2 tile block and each of the eight L2s read
+  // the whole A matrix (profiles/r05_gemm256_traffic.json: the 80 x 3 grids 307 MB against 130 MB algorithmic).  Same
+  // arithmetic per output element and per slab: the results do not change.
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x, ksplit = blockIdx.y;
+  if (gridDim.y > 1 && (flags & X4_F_SPLIT_XCD)) {
+    const int total = nwg * gridDim.y, L = blockIdx.y * nwg + blockIdx.x;
+    const int q8 = total >> 3, r8 = total & 7, x8 = L & 7;
+    const int id = (x8 < r8 ? x8 * (q8 + 1) : r8 * (q8 + 1) + (x8 - r8) * q8) + (L >> 3);
+    ksplit = id / nwg;
+    bid = -1 - (id - ksplit * nwg);                // a logical tile id, already in (column, row) order
+  }
   const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
-  const int lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  const int lid = bid < 0 ? -1 - bid : (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   const int tiles_n = nwg / tiles_m;
   const int per_group = 8 * tiles_n;
   const int first_m = (lid / per_group) * 8;
@@ -455,11 +471,11 @@ __global__ __launch_bounds__(512) void gemm_x8_kernel(const bf16_t* __restrict__
   const int m0 = tm * X4_BM, n0 = tn * X4_BN;
 
   const int nt_all = K >> 6;
-  const int kt0 = blockIdx.y * kt_per_split;
+  const int kt0 = ksplit * kt_per_split;
   const int nt = (nt_all - kt0) < kt_per_split ? (nt_all - kt0) : kt_per_split;
   if (gridDim.y > 1)
-    Cv = (flags & MH_GEMM_OUT_F32) ? (void*)(reinterpret_cast<float*>(Cv) + blockIdx.y * split_stride)
-                                   : (void*)(reinterpret_cast<bf16_t*>(Cv) + blockIdx.y * split_stride);
+    Cv = (flags & MH_GEMM_OUT_F32) ? (void*)(reinterpret_cast<float*>(Cv) + ksplit * split_stride)
+                                   : (void*)(reinterpret_cast<bf16_t*>(Cv) + ksplit * split_stride);
 
   float32_t c[4];
   {
@@ -572,6 +588,7 @@ int mh_launch_gemm_x4(const void* A, int lda, const void* B, int ldb, void* C, i
   if (x4_same_panel) flags |= X4_F_SAME_PANEL;
   if (mh_opt(MH_OPT_GEMM_ZERO_PAD)) flags |= X4_F_ZERO_PAD;
   if (mh_opt(MH_OPT_GEMM_SKIP_PAD)) flags |= X4_F_SKIP_PAD;
+  if (splits > 1 && mh_opt(MH_OPT_GEMM_SPLIT_XCD)) flags |= X4_F_SPLIT_XCD;
   if (x4_no_stores) flags |= X4_F_NO_STORES;
   if (x4_clock_probe && !aux && !(flags & (MH_GEMM_SWIGLU_FWD | MH_GEMM_SWIGLU_BWD))) { flags |= X4_F_CLOCK_PROBE; aux = x4_clock_probe; }
   if (g_mh_prof_on) mh_prof_pre(stream, 2, M, N, K, splits, flags);

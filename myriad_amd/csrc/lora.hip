@@ -777,6 +777,9 @@ int mh_launch_lora_dx_rmsnorm_bwd(const void* dx_ext, int slab_bf16, long ld, in
   if (M <= 0) return MH_OK;
   if (D % 4 || ld % 4 || ld < D + R2_ || p < 0.f || p >= 1.f || nslab < 1 || R2_ > 64) return MH_ERR_ARG;
   if (D > 4 * LXN_NT) return MH_ERR_UNSUPPORTED;
+  // a wave owns 256 consecutive columns and the kernel's barriers sit in both arms of `if (live)`: every wave has to be all live
+  // or all dead (at D % 256 != 0, e.g. 3200, one wave would arrive at both arms' barriers)
+  if (D % 256) return MH_ERR_UNSUPPORTED;
   if (R2_ != 16) return MH_ERR_UNSUPPORTED;          // r = 8 (the shipped config); r = 16 would need 128 registers of A per thread
   // rows per workgroup: as few as give one round of <= 256 workgroups (A is read once per workgroup), five at most
   int rows = M <= 256 ? 1 : (M <= 512 ? 2 : (M <= 768 ? 3 : (M <= 1024 ? 4 : 5)));

@@ -18,6 +18,7 @@ static MhOptEntry g_opts[MH_OPT_COUNT] = {
     {"attn_full", "MYRIAD_ATTN_FULL", 1, -1},
     {"lora_wgrad_mfma", "MYRIAD_LORA_WGRAD_MFMA", 1, -1},
     {"gemm_skip_pad", "MYRIAD_GEMM_SKIP_PAD", 1, -1},
+    {"gemm_split_xcd", "MYRIAD_GEMM_SPLIT_XCD", 1, -1},
 };
 
 int mh_opt(int id) {

@@ -193,7 +193,8 @@ class LoraQV:
         _, splits = ops.gemm_plan(M, D + BORDER, K)
         A = self._aqv(self.P, layer_idx)
         lib = _lib.load()
-        fused = bool(lib.mh_get_option(b"lora_norm_fused")) and D <= 4096 and 2 * r == 16
+        # the library's own condition (lora.hip: mh_launch_lora_dx_rmsnorm_bwd); an unknown option name reads as a negative error code
+        fused = lib.mh_get_option(b"lora_norm_fused") == 1 and D <= 4096 and D % 256 == 0 and 2 * r == 16
         dxn = None if fused else torch.empty((M, D), dtype=F32, device=self.dev)
         if splits > 1:
             border = torch.empty((M, BORDER), dtype=F32, device=self.dev)

@@ -42,7 +42,7 @@ def test_header_parses_and_library_exports_every_symbol():
 def test_options_are_named_switches_with_defaults():
     lib = _lib.load()
     for name in (b"slab_bf16", b"gemm_skinny", b"swiglu_fused", b"gelu_fused", b"attn_bwd_split", b"gemm_zero_pad",
-                 b"gemm256_impl", b"lora_norm_fused", b"attn_full", b"lora_wgrad_mfma", b"gemm_skip_pad"):
+                 b"gemm256_impl", b"lora_norm_fused", b"attn_full", b"lora_wgrad_mfma", b"gemm_skip_pad", b"gemm_split_xcd"):
         assert lib.mh_get_option(name) in (0, 1)
     assert lib.mh_get_option(b"no_such_option") == -1 and lib.mh_set_option(b"no_such_option", 1) == -1
     assert lib.mh_set_option(b"gelu_fused", 2) == -1

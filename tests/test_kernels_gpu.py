@@ -262,6 +262,35 @@ def test_waves_past_the_last_row_skip_their_matrix_instructions_and_change_nothi
     assert not torch.isnan(outs[0][1]).any()
 
 
+@pytest.mark.parametrize("M,N,K", [(1184, 4096, 4096), (1184, 4096, 22016), (1184, 4160, 12288), (2056, 1408, 6144), (1184, 4096, 11008),
+                                   (648, 4096, 8192), (300, 768, 4096)])
+def test_k_split_workgroups_grouped_by_split_per_xcd_change_nothing(M, N, K):
+    """256 x 256 kernel, K-split launches (option gemm_split_xcd, round 6): which workgroup computes which (tile, split) is re-mapped
+    so that one XCD's workgroups share a K range -- a permutation of the grid, the SAME bits in every slab and in the summed result:
+    grids whose tile count is / is not a multiple of eight (80, 85 = the LoRA-bordered qkv dgrad, 54, 48, 6), bf16 and f32 outputs
+    with bias, and the slab-consuming fused forms through ops.gemm's own split plan."""
+    hook = _opt_hook("gemm_split_xcd")
+    ops.ensure_workspace(torch.device(DEV))
+    a = bf(rnd(M, K, seed=251)).to(DEV)
+    b = bf(rnd(N, K, seed=252) * 0.05).to(DEV)
+    bias = rnd(N, seed=253).to(DEV)
+    k, sp = ops.gemm_plan(M, N, K)
+    outs = []
+    try:
+        for on in (1, 0):
+            hook(on)
+            outs.append((ops.gemm(a, b, bias=bias), ops.gemm(a, b, out_dtype=torch.float32), ops.gemm(a, b, bias=bias, variant=12),
+                         ops.gemm(a, b, out_dtype=torch.float32, variant=12)))
+    finally:
+        hook(1)
+    for x, y in zip(outs[0], outs[1]):
+        assert torch.equal(x, y)
+    assert relerr(outs[0][1], a.float() @ b.float().T) < 6e-3
+    assert not torch.isnan(outs[0][1]).any()
+    if (M, N, K) != (300, 768, 4096):
+        assert k == 2 and sp > 1, "the shape was meant to exercise a K-split launch of plan kernel 2"
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 4096, 4096), (8, 12288, 4160), (16, 1000, 11008), (3, 32000, 4096)])
 def test_skinny_m_weight_streaming_gemm(M, N, K):
     """M <= 16 routes to the decode weight-streaming kernel (gemv.hip)."""

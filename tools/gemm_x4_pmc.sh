@@ -10,7 +10,7 @@ M, N, K = 8192, 8192, 8192
 a = (torch.randn(M, K, device=dev) * 0.5).to(torch.bfloat16); b = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)
 out = torch.empty((M, N), dtype=torch.bfloat16, device=dev)
 for impl in (0, 1):
-    L.mhdbg_set_gemm256_impl(impl)
+    L.mh_set_option(b"gemm256_impl", impl)
     for _ in range(3): ops.gemm(a, b, out=out, variant=12)
 torch.cuda.synchronize()
 PY

@@ -282,6 +282,10 @@ def main():
         raise SystemExit("bench.py needs an MI355X (no CPU path exists for the product)")
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
+    if os.environ.get("MYRIAD_MAIN_PRIO") == "1":
+        # experiment switch: the step's main chain on a high-priority HIP stream (the look-ahead ViT / leaf / LoRA side streams
+        # keep the default priority), so that the dispatcher prefers the chain's workgroups whenever both have some pending
+        torch.cuda.set_stream(torch.cuda.Stream(device=dev, priority=-1))
     setup_seeds(42, rank)                                  # reference train.py:63-72
     cfg = full_config(llm_layers=a.llm_layers, vit_depth=a.vit_depth, qf_layers=a.qf_layers)
     weights = SyntheticWeights(cfg, dev, seed=0, arch=a.arch)   # identical frozen weights on every rank

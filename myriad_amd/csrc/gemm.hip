@@ -402,45 +402,63 @@ __global__ void splitk_reduce_kernel(const void* __restrict__ ws, void* __restri
 // is bit-identical to the two-launch form it replaces (one launch and one read of the fp32 stream less per use).
 // NORM 0: RMSNorm (y = w * h * rsqrt(mean(h^2) + eps));  NORM 1: LayerNorm (y = (h - mean) * rsqrt(var + eps) * w + nb,
 // eva_vit.py:175-179 / ImageBind transformer.py:160-163) -- each written exactly as norm.hip writes it.
-template <int NORM, int sbf>
-__global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const void* __restrict__ ws, const float* __restrict__ bias,
+// Round 6: templated on the float4 chunks a thread holds (N <= 4096: 4, else 8) and every load of the row requested up front.
+// With the run-time chunk loop each chunk was a memory round trip of its own (the store of `hout`, which may alias `res`, kept
+// the next chunk's loads behind it): four dependent trips per row.  Same expressions in the same order: same bits.
+template <int NORM, int sbf, int NIT>
+__global__ __launch_bounds__(256, NIT <= 4 ? 5 : 2) void splitk_reduce_norm_kernel(const void* __restrict__ ws, const float* __restrict__ bias,
                                                                  const float* res, float* hout, const float* __restrict__ w,
                                                                  const float* __restrict__ nb, bf16_t* __restrict__ y, int N,
                                                                  long ldr, long ldh, long ldy, long slab, int splits,
                                                                  float eps) {
   __shared__ float red[4];
   const long row = blockIdx.x;
-  float4_t hv[8];                                   // N <= 8192
+  float4_t hv[NIT];                                 // N <= 1024 * NIT
+  float4_t rv[NIT];
   float acc1 = 0.f;                                 // sum of squares (RMS) or plain sum (LayerNorm)
-  int c = 0;
-  for (int i = threadIdx.x * 4; i < N; i += 1024, ++c) {
-    float4_t sacc = slab_load4(ws, row * N + i, sbf);
-    int k = 1;
-    if (splits > 4)                                 // (the batch-8 step's 3-slab launches keep the plain loop: measured faster)
-    for (; k + 4 <= splits; k += 4) {               // ascending order, four loads in flight (the batch-1 step's 8-11 slabs)
-      float4_t p[4];
+  if (res) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) p[u] = slab_load4(ws, (long)(k + u) * slab + row * N + i, sbf);
+    for (int c = 0; c < NIT; ++c) {
+      const int i = threadIdx.x * 4 + c * 1024;
+      if (i < N) rv[c] = *reinterpret_cast<const float4_t*>(res + row * ldr + i);
+    }
+  }
 #pragma unroll
-      for (int u = 0; u < 4; ++u) { sacc[0] += p[u][0]; sacc[1] += p[u][1]; sacc[2] += p[u][2]; sacc[3] += p[u][3]; }
+  for (int c = 0; c < NIT; ++c) {
+    const int i = threadIdx.x * 4 + c * 1024;
+    if (i < N) {
+      float4_t sacc = slab_load4(ws, row * N + i, sbf);
+      int k = 1;
+      if (splits > 4)                                 // (the batch-8 step's 3-slab launches keep the plain loop: measured faster)
+      for (; k + 4 <= splits; k += 4) {               // ascending order, four loads in flight (the batch-1 step's 8-11 slabs)
+        float4_t p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = slab_load4(ws, (long)(k + u) * slab + row * N + i, sbf);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { sacc[0] += p[u][0]; sacc[1] += p[u][1]; sacc[2] += p[u][2]; sacc[3] += p[u][3]; }
+      }
+      for (; k < splits; ++k) {
+        const float4_t p = slab_load4(ws, (long)k * slab + row * N + i, sbf);
+        sacc[0] += p[0]; sacc[1] += p[1]; sacc[2] += p[2]; sacc[3] += p[3];
+      }
+      hv[c] = sacc;
     }
-    for (; k < splits; ++k) {
-      const float4_t p = slab_load4(ws, (long)k * slab + row * N + i, sbf);
-      sacc[0] += p[0]; sacc[1] += p[1]; sacc[2] += p[2]; sacc[3] += p[3];
+  }
+#pragma unroll
+  for (int c = 0; c < NIT; ++c) {
+    const int i = threadIdx.x * 4 + c * 1024;
+    if (i < N) {
+      float v[4] = {hv[c][0] * 1.0f, hv[c][1] * 1.0f, hv[c][2] * 1.0f, hv[c][3] * 1.0f};
+      if (bias) {
+        const float4_t b4 = *reinterpret_cast<const float4_t*>(bias + i);
+        v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
+      }
+      if (res) { v[0] += rv[c][0]; v[1] += rv[c][1]; v[2] += rv[c][2]; v[3] += rv[c][3]; }
+      hv[c] = (float4_t){v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<float4_t*>(hout + row * ldh + i) = hv[c];
+      if (NORM == 0) acc1 += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+      else acc1 += v[0] + v[1] + v[2] + v[3];
     }
-    float v[4] = {sacc[0] * 1.0f, sacc[1] * 1.0f, sacc[2] * 1.0f, sacc[3] * 1.0f};
-    if (bias) {
-      const float4_t b4 = *reinterpret_cast<const float4_t*>(bias + i);
-      v[0] += b4[0]; v[1] += b4[1]; v[2] += b4[2]; v[3] += b4[3];
-    }
-    if (res) {
-      const float4_t r4 = *reinterpret_cast<const float4_t*>(res + row * ldr + i);
-      v[0] += r4[0]; v[1] += r4[1]; v[2] += r4[2]; v[3] += r4[3];
-    }
-    hv[c] = (float4_t){v[0], v[1], v[2], v[3]};
-    *reinterpret_cast<float4_t*>(hout + row * ldh + i) = hv[c];
-    if (NORM == 0) acc1 += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
-    else acc1 += v[0] + v[1] + v[2] + v[3];
   }
   float mean = 0.f, r;
   if (NORM == 0) {
@@ -448,29 +466,35 @@ __global__ __launch_bounds__(256) void splitk_reduce_norm_kernel(const void* __r
   } else {
     mean = block_sum<4>(acc1, red) / N;
     float ss = 0.f;
-    c = 0;
-    for (int i = threadIdx.x * 4; i < N; i += 1024, ++c) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) ss += (hv[c][e] - mean) * (hv[c][e] - mean);
+    for (int c = 0; c < NIT; ++c) {
+      const int i = threadIdx.x * 4 + c * 1024;
+      if (i < N) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) ss += (hv[c][e] - mean) * (hv[c][e] - mean);
+      }
     }
     r = rsqrtf(block_sum<4>(ss, red) / N + eps);
   }
-  c = 0;
-  for (int i = threadIdx.x * 4; i < N; i += 1024, ++c) {
-    const float4_t g = *reinterpret_cast<const float4_t*>(w + i);
-    float o[4];
-    if (NORM == 0) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = g[e] * (hv[c][e] * r);
-    } else {
-      const float4_t bb = *reinterpret_cast<const float4_t*>(nb + i);
+  for (int c = 0; c < NIT; ++c) {
+    const int i = threadIdx.x * 4 + c * 1024;
+    if (i < N) {
+      const float4_t g = *reinterpret_cast<const float4_t*>(w + i);
+      float o[4];
+      if (NORM == 0) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = (hv[c][e] - mean) * r * g[e] + bb[e];
+        for (int e = 0; e < 4; ++e) o[e] = g[e] * (hv[c][e] * r);
+      } else {
+        const float4_t bb = *reinterpret_cast<const float4_t*>(nb + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (hv[c][e] - mean) * r * g[e] + bb[e];
+      }
+      uint2 pk;
+      pk.x = pack_bf2(o[0], o[1]);
+      pk.y = pack_bf2(o[2], o[3]);
+      *reinterpret_cast<uint2*>(y + row * ldy + i) = pk;
     }
-    uint2 pk;
-    pk.x = pack_bf2(o[0], o[1]);
-    pk.y = pack_bf2(o[2], o[3]);
-    *reinterpret_cast<uint2*>(y + row * ldy + i) = pk;
   }
 }
 
@@ -752,12 +776,15 @@ static int gemm_residual_norm(int norm, const void* A, int lda, const void* B, i
     int sbf = 0;
     int rc = run_splitk(g, splits, wsp, stream, /*reduce=*/false, &sbf);
     if (rc) return rc;
-#define RN_LAUNCH(NORM_, SBF_)                                                                                              \
-  hipLaunchKernelGGL((splitk_reduce_norm_kernel<NORM_, SBF_>), dim3(M), dim3(256), 0, stream, (const void*)wsp, bias, residual, H, \
+#define RN_LAUNCH1(NORM_, SBF_, NIT_)                                                                                       \
+  hipLaunchKernelGGL((splitk_reduce_norm_kernel<NORM_, SBF_, NIT_>), dim3(M), dim3(256), 0, stream, (const void*)wsp, bias, residual, H, \
                      norm_w, norm_b, (bf16_t*)Y, N, (long)ldr, (long)ldh, ldy, (long)M * N, sp, eps)
+#define RN_LAUNCH(NORM_, SBF_)                                                                                              \
+  do { if (N <= 4096) RN_LAUNCH1(NORM_, SBF_, 4); else RN_LAUNCH1(NORM_, SBF_, 8); } while (0)
     if (norm == 0) { if (sbf) RN_LAUNCH(0, 1); else RN_LAUNCH(0, 0); }
     else { if (sbf) RN_LAUNCH(1, 1); else RN_LAUNCH(1, 0); }
 #undef RN_LAUNCH
+#undef RN_LAUNCH1
     MH_CHECK_LAUNCH();
     return MH_OK;
   }

@@ -140,6 +140,16 @@ class ParamStore:
         host = torch.tensor([int(steps.get(m, 0)) for m in self.modules] or [0], dtype=torch.int32)
         self.steps_dev.copy_(host.to(self.dev))
 
+    def module_range(self, module: str, decays: bool = True):
+        """(start, end) of one module's contiguous run inside a weight-decay group of the flat buffers, or None."""
+        if module not in self.modules:
+            return None
+        mi = self.modules.index(module)
+        for m2, a, b, d in self.ranges:
+            if m2 == mi and d == decays:
+                return a, b
+        return None
+
     def adamw_module(self, module: str, lr: float, weight_decay: float = 0.05, beta2: float = 0.999) -> None:
         """The gated AdamW of ONE module's ranges, on the current stream (single-process training: a module whose gradient is
         complete may be updated while the rest of the backward still runs; adamw_step(..., skip={module}) then leaves it out
@@ -153,23 +163,26 @@ class ParamStore:
     def adamw_step(self, lr: float, weight_decay: float = 0.05, beta2: float = 0.999, grad_scale: float = 1.0, shard=None,
                    skip=()):
         """torch.optim.AdamW semantics (runner_base.py:132-137), fused, on the flat buffers; modules unused on every rank
-        this step are left alone (see class docstring).  `shard` = (lo, hi): update only that slice of the flat buffer
-        (DataParallel mode 'rs_ag': each rank owns 1/world of the optimiser state).  `skip`: modules adamw_module() already
+        this step are left alone (see class docstring).  `shard` = (lo, hi) or a list of such: update only those slices of the
+        flat buffer (DataParallel mode 'rs_ag': each rank owns 1/world of every exchange segment's optimiser state).  `skip`: modules adamw_module() already
         updated this step."""
         self.step += 1
-        if shard is not None and (shard[0] > 0 or shard[1] < self.total):
-            self.moments_complete = False                         # DataParallel.gather_state() restores it
+        pieces = None
+        if shard is not None:
+            pieces = [tuple(shard)] if isinstance(shard[0], int) else [tuple(p) for p in shard]
+            if sum(hi - lo for lo, hi in pieces) < self.total:
+                self.moments_complete = False                     # DataParallel.gather_state() restores it
         skip_idx = {self.modules.index(m) for m in skip if m in self.modules}
-        for mi, a, b, decays in self.ranges:
+        for mi, a0, b0, decays in self.ranges:
             if mi in skip_idx:
                 continue
-            if shard is not None:
-                a, b = max(a, shard[0]), min(b, shard[1])
+            for lo, hi in (pieces if pieces is not None else [(a0, b0)]):
+                a, b = max(a0, lo), min(b0, hi)
                 if a >= b:
                     continue
-            ops.adamw_gated(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b], lr,
-                            weight_decay if decays else 0.0, self.used[mi:mi + 1], self.steps_dev[mi:mi + 1], beta2=beta2,
-                            grad_scale=grad_scale)
+                ops.adamw_gated(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b], lr,
+                                weight_decay if decays else 0.0, self.used[mi:mi + 1], self.steps_dev[mi:mi + 1], beta2=beta2,
+                                grad_scale=grad_scale)
         if self.modules:
             ops.adamw_bump(self.used, self.steps_dev)
 
@@ -578,11 +591,16 @@ class MyriadHIP(nn.Module):
         loop accumulates over `accum_grad_iters` backward calls before it steps (base_task.py:256-271)."""
         return self._has_grads and any(prm.grad is not None for prm in self._params.values())
 
-    def backward(self, gscale: float = 1.0, accumulate: bool = False, early_adamw=None):
+    def backward(self, gscale: float = 1.0, accumulate: bool = False, early_adamw=None, early_exchange=None):
         """Explicit backward of the last forward: fills the flat gradient buffer, multiplied by `gscale` (a GradScaler's
         loss scale; 1.0 otherwise).  Modules this step did not use keep zero gradients AND a zero use flag, so the gated
         AdamW leaves them untouched unless another rank used them (ParamStore).  With `accumulate` the result is added to
-        the gradients already in the buffer."""
+        the gradients already in the buffer.
+        early_exchange = (DataParallel, segment index): the data-parallel exchange of that segment of the gradient buffer -- the
+        map tokenizer's conv head, 91 % of the bytes -- is started as soon as the tokenizer's backward is queued, on the stream
+        that ran it, so the collective runs under the Q-Former / adaptor backward (runner_base.py:94-98: DDP's bucketed overlap;
+        here two buckets, cut where the backward's own order puts the bytes).  Every rank issues it at the same point, also a rank
+        whose prompt stage skipped the tokenizer (its zeros are its contribution)."""
         c = self._ctx
         if c is None:
             raise RuntimeError("backward() without a training forward")
@@ -644,10 +662,14 @@ class MyriadHIP(nn.Module):
                     # leaf stream beside the Q-Former backward instead of at the tail of the step.  Same kernel, same inputs.
                     self.store.adamw_module("VETokenizer", early_adamw[0], early_adamw[1])
                     self._early_done = {"VETokenizer"}
+                if early_exchange is not None:
+                    early_exchange[0].start_part(self.store.flat_g_comm, self.store.total, early_exchange[1])
                 leaf_ev = torch.cuda.Event()
                 leaf_ev.record()
         else:
             leaf_ev, leaf_keep = None, None
+            if early_exchange is not None:                # unused at this rank's prompt stage: the segment's zeros travel now
+                early_exchange[0].start_part(self.store.flat_g_comm, self.store.total, early_exchange[1])
         dq, denc = self.qformer.backward(dqo)
         ins_ev, ins_keep = None, None
         if c["use_ins"]:
@@ -833,7 +855,8 @@ class MyriadHIP(nn.Module):
                 # frozen ViT forward (independent of the update) under it, then apply the delayed AdamW.
                 vit_out = self.visual_encoder.forward(self._image_of(samples))
                 self.finish_update()
-            if self._accum_count == 0 and self._leaf_aside and os.environ.get("MYRIAD_EARLY_ZERO", "1") != "0":
+            if (self._accum_count == 0 and self._leaf_aside and self._dev.type == "cuda"
+                    and os.environ.get("MYRIAD_EARLY_ZERO", "1") != "0"):
                 # the gradient buffer's zero fill (460 MB, ~55 us) leaves the chain between forward and backward: nothing writes a
                 # gradient before the backward, and the last update (main stream, and the leaf stream itself) has read them
                 aux, main = self._side_stream("leaf"), torch.cuda.current_stream()
@@ -842,13 +865,25 @@ class MyriadHIP(nn.Module):
                     self.store.flat_g_comm.zero_()
                     self._g_zeroed = torch.cuda.Event()
                     self._g_zeroed.record(aux)
-            loss = self._forward_impl(samples, True, vit_out=vit_out)
+            try:
+                loss = self._forward_impl(samples, True, vit_out=vit_out)
+            except Exception:
+                self._g_zeroed = None                 # a forward that raised ("no valid labels"): no stale event for a later backward()
+                raise
             accumulate = self._accum_count > 0                   # > 0: the flat buffer holds gradients no update has consumed
             due = accum_update_due(self._accum_count + 1, accum_grad_iters, accum_index)
             # no gradient exchange, no accumulation window: modules whose gradient is complete early are updated early (backward())
+            # (world == 1 as well: a caller-scaled update -- `world` > 1 without dp / allreduce -- must see ONE grad_scale)
             early = (lr, weight_decay) if (due and not accumulate and (dp is None or dp.world == 1) and allreduce is None
-                                           and os.environ.get("MYRIAD_EARLY_ADAMW", "1") != "0") else None
-            self.backward(accumulate=accumulate, early_adamw=early)
+                                           and world == 1 and os.environ.get("MYRIAD_EARLY_ADAMW", "1") != "0") else None
+            # data parallel with the exchange overlapped: the tokenizer's segment of the gradient buffer starts its collective from
+            # inside the backward (backward(): early_exchange); accumulation windows exchange the window's sum at its end instead
+            early_x = None
+            if (dp is not None and dp.world > 1 and overlap and due and not accumulate and self.arch == "myriad"
+                    and hasattr(dp, "start_part") and os.environ.get("MYRIAD_DP_EARLY", "1") != "0"):
+                k = self._dp_segment(dp)
+                early_x = (dp, k) if k is not None else None
+            self.backward(accumulate=accumulate, early_adamw=early, early_exchange=early_x)
             self._accum_count += 1
             if not due:
                 return loss                                   # inside an accumulation window: no exchange, no update
@@ -860,7 +895,7 @@ class MyriadHIP(nn.Module):
                 shard = None
                 if dp is not None and dp.world > 1:
                     dp.allreduce(self.store.flat_g_comm, self.store.total)
-                    shard = dp.shard(self.store.total)[:2] if dp.mode == "rs_ag" else None
+                    shard = self._dp_shards(dp)
                 elif allreduce is not None:
                     allreduce(self.store.flat_g_comm)
                     world = max(world, 1)
@@ -869,6 +904,30 @@ class MyriadHIP(nn.Module):
                 if shard is not None:
                     dp.gather_params(self.store.flat_p)
         return loss
+
+    def _dp_shards(self, dp):
+        """rs_ag: the slices of the flat buffers this rank's AdamW owns (one per exchange segment); None: the whole buffer."""
+        if getattr(dp, "mode", "allreduce") != "rs_ag":
+            return None
+        return dp.shards(self.store.total) if hasattr(dp, "shards") else [dp.shard(self.store.total)[:2]]
+
+    def _dp_segment(self, dp):
+        """Cut the exchange at the map tokenizer's conv-head weights (its weight-decay run of the flat buffer: 105 M of the 115 M
+        trainables) and return that segment's index, or None when the model has no such run worth an exchange of its own.  The
+        cut points are rounded inwards to multiples of 32 elements, so that at 2 / 4 / 8 ranks every segment's reduce-scatter
+        tiles it exactly (ParamStore pads the total the same way)."""
+        if getattr(self, "_dp_seg_of", None) is not None and self._dp_seg_of[0] is dp:
+            return self._dp_seg_of[1]
+        k = None
+        rng = self.store.module_range("VETokenizer", True)
+        if rng is not None:
+            a, b = ops.round_up(rng[0], 32), rng[1] // 32 * 32
+            if b - a >= (1 << 20):
+                dp.set_segments(self.store.total, [a, b])
+                segs = dp.segments(self.store.total)
+                k = segs.index((a, b)) if (a, b) in segs else None
+        self._dp_seg_of = (dp, k)
+        return k
 
     def finish_update(self):
         """Apply a delayed optimiser update (overlap mode): wait for the gradient exchange, if any, then fused AdamW."""
@@ -879,7 +938,7 @@ class MyriadHIP(nn.Module):
                 self.store.adamw_step(lr, wd)
                 return
             dp.wait()
-            shard = dp.shard(self.store.total)[:2] if getattr(dp, "mode", "allreduce") == "rs_ag" else None
+            shard = self._dp_shards(dp)
             self.store.adamw_step(lr, wd, grad_scale=1.0 / dp.world, shard=shard)
             if shard is not None:
                 dp.gather_params(self.store.flat_p)

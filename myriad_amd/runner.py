@@ -172,7 +172,9 @@ class DataParallel:
         self.world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
         self.device = device
-        self.mode = mode or os.environ.get("MYRIAD_DP_MODE", "allreduce")
+        # default: one all-reduce at 2 ranks; reduce-scatter + sharded AdamW + all-gather from 4 ranks on (every rank then runs
+        # 1/world of the optimiser's HBM traffic and the second half of the ring moves parameters instead of gradients)
+        self.mode = mode or os.environ.get("MYRIAD_DP_MODE") or ("rs_ag" if self.world >= 4 else "allreduce")
         if self.mode not in ("allreduce", "rs_ag"):
             raise ValueError(f"MYRIAD_DP_MODE={self.mode}: expected allreduce or rs_ag")
         gd = grad_dtype or os.environ.get("MYRIAD_DP_GRAD_DTYPE", "f32")
@@ -182,6 +184,13 @@ class DataParallel:
             self.side = torch.cuda.Stream(device=device)
         self._pending = None
         self._bufs = {}
+        # The gradient buffer may be exchanged in SEGMENTS (set_segments): a segment whose gradient is complete early -- the map
+        # tokenizer's 105 M-weight head, 91 % of the bytes, done right behind the LLaMA backward -- starts its collective while the
+        # rest of the backward still runs (start_part); start() then exchanges what is left.  The segmentation is fixed for the life
+        # of the object: in 'rs_ag' mode it also defines which slices of parameters and Adam moments this rank owns (shards()).
+        self._segs = None                 # [(lo, hi)] tiling [0, total)
+        self._seg_total = None
+        self._started = set()             # segment indices already started in the exchange under way
         # on RCCL (backend nccl) the exchange goes through the library's own verbs -- mh_allreduce_start_dt /
         # mh_reduce_scatter_start / mh_allgather_start / mh_allreduce_wait on an mh_ctx that owns the communicator and the side
         # stream (include/myriad_hip.h) -- both modes, both wire types; the process group is then only the channel that hands
@@ -222,12 +231,38 @@ class DataParallel:
             buf = self._bufs[k] = torch.zeros(n, dtype=dtype, device=device)
         return buf
 
-    # ---- shard geometry (rs_ag): [0, total) split into `world` equal pieces of a multiple of 4 elements
-    def shard(self, total: int):
-        per = (total + self.world - 1) // self.world
+    # ---- segments and shard geometry
+    def set_segments(self, total: int, cuts) -> None:
+        """Cut the gradient buffer [0, total) at the interior points `cuts` (each a multiple of 4; multiples of 4 * world keep
+        the reduce-scatter in place).  Call once, before the first exchange, identically on every rank."""
+        if self._segs is not None:
+            if self._seg_total != total:
+                raise ValueError("DataParallel.set_segments: the segmentation is fixed once set (Adam moments are sharded by it)")
+            return
+        pts = [0] + sorted({int(c) for c in cuts if 0 < int(c) < total}) + [total]
+        if any(c % 4 for c in pts):
+            raise ValueError("DataParallel.set_segments: cut points must be multiples of 4 elements")
+        self._segs = [(a, b) for a, b in zip(pts[:-1], pts[1:]) if b > a]
+        self._seg_total = total
+
+    def segments(self, total: int):
+        return self._segs if (self._segs is not None and self._seg_total == total) else [(0, total)]
+
+    def _piece(self, lo: int, hi: int):
+        """This rank's piece of segment [lo, hi): `world` equal pieces of a multiple of 4 elements.  -> (lo_r, hi_r, per)"""
+        n = hi - lo
+        per = (n + self.world - 1) // self.world
         per = (per + 3) // 4 * 4
-        lo = min(self.rank * per, total)
-        return lo, min(lo + per, total), per
+        a = min(lo + self.rank * per, hi)
+        return a, min(a + per, hi), per
+
+    def shards(self, total: int):
+        """rs_ag: the slices of the flat buffers this rank owns (one per segment): its AdamW runs on exactly these."""
+        return [self._piece(lo, hi)[:2] for lo, hi in self.segments(total)]
+
+    def shard(self, total: int):
+        """The single-segment form of shards(): (lo, hi, per) of this rank's piece of [0, total)."""
+        return self._piece(0, total)
 
     def _run(self, fn):
         if self.side is not None:
@@ -253,79 +288,110 @@ class DataParallel:
         else:
             self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
 
-    def _reduce_scatter(self, body: torch.Tensor, per: int) -> None:
-        """Sum over ranks; rank r ends up with the sum in body[r*per:(r+1)*per] (the rest of `body` is left unspecified)."""
+    def _reduce_scatter(self, body: torch.Tensor, k: int = 0) -> None:
+        """Sum over ranks of one segment; rank r ends up with the sum in its own piece of `body` (the rest of `body` is left
+        unspecified)."""
         n = body.numel()
+        lo, hi, per = self._piece(0, n)
         if n == per * self.world:                         # the store pads its buffers so that this holds at 2 / 4 / 8 ranks
             padded = body
         else:                                             # other rank counts: one persistent padded copy, no per-step allocation
-            padded = self._persistent("rs_pad", per * self.world, body.dtype, body.device)
+            padded = self._persistent(f"rs_pad{k}", per * self.world, body.dtype, body.device)
             padded[:n].copy_(body)
         w = self._cast(padded, self.grad_dtype)
         if self._gloo:                                    # gloo has no reduce_scatter: all-reduce and keep the own piece
             self.dist.all_reduce(w, op=self.dist.ReduceOp.SUM)
             mine = w[self.rank * per:(self.rank + 1) * per]
         else:
-            mine = self._persistent("rs_mine", per, w.dtype, w.device)
+            mine = self._persistent(f"rs_mine{k}", per, w.dtype, w.device)
             self.dist.reduce_scatter_tensor(mine, w, op=self.dist.ReduceOp.SUM)
-        lo, hi, _ = self.shard(n)
         body[lo:hi].copy_(self._cast(mine, body.dtype)[:hi - lo])
 
-    def start(self, flat_g_comm: torch.Tensor, n_grad: Optional[int] = None) -> None:
-        """Launch the exchange of [gradients (n_grad elements) | flags].  n_grad=None: the whole buffer is gradients."""
-        if self.world == 1:
-            return
-        n_grad = flat_g_comm.numel() if n_grad is None else n_grad
-
+    def _exchange(self, flat_g_comm: torch.Tensor, n_grad: int, ks, with_flags: bool) -> None:
+        """Queue the collectives of the segments `ks` (indices into segments(n_grad)) and, with_flags, of the use-flag tail
+        behind the current stream."""
+        segs = self.segments(n_grad)
+        n_all = flat_g_comm.numel()
         if self.ctx is not None:
-            self._ctx_start(flat_g_comm, n_grad)
+            self._ctx_exchange(flat_g_comm, n_grad, ks, with_flags)
             return
 
         def go():
-            if self.mode == "allreduce":
-                self._all_reduce(flat_g_comm)
-            else:
-                if n_grad < flat_g_comm.numel():
-                    self.dist.all_reduce(flat_g_comm[n_grad:], op=self.dist.ReduceOp.SUM)
-                self._reduce_scatter(flat_g_comm[:n_grad], self.shard(n_grad)[2])
-            ev = torch.cuda.Event() if flat_g_comm.is_cuda else None
-            if ev is not None:
-                ev.record()
-            self._pending = ev if ev is not None else True
+            for k in ks:
+                lo, hi = segs[k]
+                if self.mode == "allreduce":
+                    # the flag tail rides the all-reduce of the last segment (one call for [.. gradients | flags])
+                    ext = n_all if (with_flags and hi == n_grad) else hi
+                    self._all_reduce(flat_g_comm[lo:ext])
+                else:
+                    self._reduce_scatter(flat_g_comm[lo:hi], k)
+            if with_flags and n_grad < n_all and (self.mode != "allreduce" or (len(segs) - 1) not in ks):
+                self.dist.all_reduce(flat_g_comm[n_grad:], op=self.dist.ReduceOp.SUM)
+            self._pending = True
         self._run(go)
 
-    def _ctx_start(self, flat_g_comm: torch.Tensor, n_grad: int) -> None:
+    def start_part(self, flat_g_comm: torch.Tensor, n_grad: int, k: int) -> None:
+        """Start the exchange of segment k (see set_segments) NOW, ordered behind the current stream: the caller guarantees that
+        this segment's gradient is complete there.  Every rank calls it at the same point of its step, also a rank whose step
+        did not touch the segment's module (its zeros are its contribution).  start() later exchanges the other segments."""
+        if self.world == 1:
+            return
+        if k in self._started:
+            raise RuntimeError(f"DataParallel.start_part: segment {k} was already started in this exchange")
+        self._started.add(k)
+        self._exchange(flat_g_comm, n_grad, [k], with_flags=False)
+
+    def start(self, flat_g_comm: torch.Tensor, n_grad: Optional[int] = None) -> None:
+        """Launch the exchange of [gradients (n_grad elements) | flags] -- every segment start_part() has not started yet, and the
+        flags.  n_grad=None: the whole buffer is gradients."""
+        if self.world == 1:
+            return
+        n_grad = flat_g_comm.numel() if n_grad is None else n_grad
+        ks = [k for k in range(len(self.segments(n_grad))) if k not in self._started]
+        self._started = set()
+        self._exchange(flat_g_comm, n_grad, ks, with_flags=True)
+
+    def _ctx_exchange(self, flat_g_comm: torch.Tensor, n_grad: int, ks, with_flags: bool) -> None:
         """The exchange through the library's verbs.  Casts (bf16 wire) run on the current stream in front of / behind the
         verbs, which queue on the context's side stream; what has to happen after the wait is kept in self._pending."""
         ctx, bf = self.ctx, self.grad_dtype == torch.bfloat16
-        after = []
+        segs = self.segments(n_grad)
+        n_all = flat_g_comm.numel()
+        after = self._pending if isinstance(self._pending, list) else []
         from . import ops
-        if self.mode == "allreduce":
-            if bf:
-                # the wire copy lives in a persistent buffer: the verb reads it on the context's side stream, which torch's
-                # caching allocator knows nothing about -- a per-step tensor could be handed out again while RCCL still reads it
-                w = ops.to_bf16(flat_g_comm, out=self._persistent("ar_wire", flat_g_comm.numel(), torch.bfloat16, flat_g_comm.device))
-                ctx.start(w)
-                after.append(lambda: ops.to_f32(w, out=flat_g_comm))
+        # the wire copy lives in a persistent buffer: the verb reads it on the context's side stream, which torch's caching
+        # allocator knows nothing about -- a per-step tensor could be handed out again while RCCL still reads it (ADVICE r4)
+        wire = self._persistent("wire", n_all, torch.bfloat16, flat_g_comm.device) if bf else None
+        for k in ks:
+            lo, hi = segs[k]
+            if self.mode == "allreduce":
+                ext = n_all if (with_flags and hi == n_grad) else hi
+                t = flat_g_comm[lo:ext]
+                if bf:
+                    w = ops.to_bf16(t, out=wire[lo:ext])
+                    ctx.start(w)
+                    after.append(lambda w=w, t=t: ops.to_f32(w, out=t))
+                else:
+                    ctx.start(t)
             else:
-                ctx.start(flat_g_comm)
-        else:
-            if n_grad < flat_g_comm.numel():
-                ctx.start(flat_g_comm[n_grad:])                   # the use flags: a few floats, always fp32
-            body = flat_g_comm[:n_grad]
-            lo, hi, per = self.shard(n_grad)
-            if n_grad == per * self.world:                        # the store pads its buffers so that this holds at 2 / 4 / 8 ranks
-                padded = body
-            else:
-                padded = self._persistent("rs_pad", per * self.world, body.dtype, body.device)
-                padded[:n_grad].copy_(body)
-            if bf:      # persistent wire buffer (ADVICE r4: a per-step cast result was freed while the side stream still read it)
-                w = ops.to_bf16(padded, out=self._persistent("rs_wire", padded.numel(), torch.bfloat16, padded.device))
-            else:
-                w = padded
-            mine = self._persistent("rs_mine", per, w.dtype, w.device)
-            ctx.reduce_scatter(w, mine)
-            after.append(lambda: body[lo:hi].copy_(self._cast(mine, body.dtype)[:hi - lo]))
+                body = flat_g_comm[lo:hi]
+                n = hi - lo
+                a, b, per = self._piece(0, n)
+                if n == per * self.world:                         # the store pads its buffers so that this holds at 2 / 4 / 8 ranks
+                    padded = body
+                else:
+                    padded = self._persistent(f"rs_pad{k}", per * self.world, body.dtype, body.device)
+                    padded[:n].copy_(body)
+                if bf:
+                    w = wire[lo:hi] if padded is body else self._persistent(f"rs_wire{k}", padded.numel(), torch.bfloat16, padded.device)
+                    ops.to_bf16(padded, out=w)
+                else:
+                    w = padded
+                mine = self._persistent(f"rs_mine{k}", per, w.dtype, w.device)
+                ctx.reduce_scatter(w, mine)
+                after.append(lambda body=body, mine=mine, a=a, b=b: body[a:b].copy_(self._cast(mine, body.dtype)[:b - a]))
+        if with_flags and n_grad < n_all and (self.mode != "allreduce" or (len(segs) - 1) not in ks):
+            ctx.start(flat_g_comm[n_grad:])                       # the use flags: a few floats, always fp32
         self._pending = after
 
     def wait(self) -> None:
@@ -345,28 +411,34 @@ class DataParallel:
         self.wait()
 
     def gather_params(self, flat_p: torch.Tensor) -> None:
-        """rs_ag: after the sharded AdamW every rank holds fresh parameters for its shard only; all-gather them in place."""
+        """rs_ag: after the sharded AdamW every rank holds fresh parameters for its pieces only; all-gather them in place,
+        segment by segment."""
         if self.world == 1 or self.mode != "rs_ag":
             return
-        n = flat_p.numel()
-        lo, hi, per = self.shard(n)
-        if self.ctx is not None and n == per * self.world:
-            mine = self._persistent("ag_mine", per, flat_p.dtype, flat_p.device)
-            mine.copy_(flat_p[lo:hi])
-            self.ctx.all_gather(mine, flat_p)
+        total = flat_p.numel()
+        waited = False
+        for k, (s_lo, s_hi) in enumerate(self.segments(total)):
+            seg = flat_p[s_lo:s_hi]
+            n = s_hi - s_lo
+            lo, hi, per = self._piece(0, n)
+            if self.ctx is not None and n == per * self.world:
+                mine = self._persistent(f"ag_mine{k}", per, flat_p.dtype, flat_p.device)
+                mine.copy_(seg[lo:hi])
+                self.ctx.all_gather(mine, seg)
+                waited = True
+                continue
+            if self._gloo or n != per * self.world:
+                mine = torch.zeros(per, dtype=flat_p.dtype, device=flat_p.device)
+                mine[:hi - lo].copy_(seg[lo:hi])
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                self.dist.all_gather(parts, mine)
+                seg.copy_(torch.cat(parts)[:n])
+            else:
+                mine = self._persistent(f"ag_mine{k}", per, flat_p.dtype, flat_p.device)
+                mine.copy_(seg[lo:hi])                    # a copy: input and output may not alias
+                self.dist.all_gather_into_tensor(seg, mine)
+        if waited:
             self.ctx.wait()
-            return
-        if self._gloo or n != per * self.world:
-            mine = torch.zeros(per, dtype=flat_p.dtype, device=flat_p.device)
-            mine[:hi - lo].copy_(flat_p[lo:hi])
-            parts = [torch.empty_like(mine) for _ in range(self.world)]
-            self.dist.all_gather(parts, mine)
-            full = torch.cat(parts)[:n]
-            flat_p.copy_(full)
-        else:
-            mine = self._persistent("ag_mine", per, flat_p.dtype, flat_p.device)
-            mine.copy_(flat_p[lo:hi])                     # a copy: input and output may not alias
-            self.dist.all_gather_into_tensor(flat_p, mine)
 
     def gather_state(self, store) -> None:
         """rs_ag: collect the Adam moments of every shard (before a checkpoint is written).  A collective: every rank calls it."""

@@ -228,6 +228,79 @@ def test_exchange_modes_world2_gloo():
             assert torch.equal(got[0][key][3], got[1][key][3])        # every rank ends with the same parameters
 
 
+def _dp_segments_worker(rank, world, port, q):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_grad, n_flags = 4096 + 32 * 37, 4                  # total and both cut points multiples of 32, as ParamStore / _dp_segment make them
+    cuts = [256, 256 + 32 * 100]                         # [small head | the early segment | tail]
+    out = {}
+    for mode, gd in (("allreduce", "f32"), ("allreduce", "bf16"), ("rs_ag", "f32"), ("rs_ag", "bf16")):
+        res = []
+        for segmented in (False, True):
+            torch.manual_seed(300 + rank)
+            comm = torch.cat([torch.randn(n_grad), torch.tensor([1.0, float(rank), 0.0, 1.0])])
+            dp = DataParallel(device=None, mode=mode, grad_dtype=gd)
+            if segmented:
+                dp.set_segments(n_grad, cuts)
+                assert dp.segments(n_grad) == [(0, 256), (256, 3456), (3456, n_grad)]
+                dp.start_part(comm, n_grad, 1)           # the early segment first, as MyriadHIP.backward issues it ...
+                dp.start(comm, n_grad)                   # ... then everything else + the flags
+                dp.wait()
+                try:
+                    dp.set_segments(n_grad + 32, cuts)   # the segmentation is fixed once set
+                    raise AssertionError("set_segments accepted a second geometry")
+                except ValueError:
+                    pass
+            else:
+                dp.allreduce(comm, n_grad)
+            pieces = dp.shards(n_grad)
+            assert len(pieces) == (3 if segmented else 1)
+            p = torch.zeros(n_grad)
+            if mode == "rs_ag":
+                for lo, hi in pieces:
+                    p[lo:hi] = -comm[lo:hi]
+                dp.gather_params(p)
+            else:
+                p = -comm[:n_grad].clone()
+            res.append((comm[n_grad:].numpy().copy(), p.numpy().copy(), pieces))
+        out[(mode, gd)] = res
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_segmented_exchange_equals_the_single_exchange_gloo(world):
+    """the gradient buffer exchanged in segments -- the map tokenizer's segment started early (start_part),
+    the rest + the use flags at the end of the backward (start) -- hands every rank the same sums as ONE exchange of the whole
+    buffer, in both modes and both wire types (element-wise sums: bit-equal also on the bf16 wire), and in rs_ag every rank owns
+    one piece of EVERY segment (its AdamW shards) and gathers all of them."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_segments_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for key in got[0]:
+        for r in range(world):
+            (f0, p0, pc0), (f1, p1, pc1) = got[r][key]
+            assert (f0 == f1).all() and f0.tolist() == [float(world), sum(range(world)), 0.0, float(world)]
+            if world == 2:
+                assert (p0 == p1).all(), (key, r)                  # segmented == single, bit for bit (a two-term sum has one order)
+            else:                                                  # gloo's ring adds four terms in an order that depends on the chunking
+                tol = 1e-5 if key[1] == "f32" else 3e-2
+                assert np.allclose(p0, p1, rtol=0, atol=tol * (1 + np.abs(p0).max())), (key, r)
+            assert (p1 == got[0][key][1][1]).all()                 # and every rank holds the same result
+            if key[0] == "rs_ag":
+                assert pc1 == [(lo + r * ((hi - lo) // world), lo + (r + 1) * ((hi - lo) // world)) for lo, hi in
+                               ((0, 256), (256, 3456), (3456, 4096 + 32 * 37))]
+
+
 def _dp_world4_worker(rank, world, port, q):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))

@@ -255,11 +255,6 @@ def test_composite_step_vs_golden(composite, arch, stage):
         assert float(model.store.g["VETokenizer.meta_net.15.weight"].abs().max()) == 0
 
 
-# bias gradients of the deeper conv layers against the plain fp32 forward (element-wise, of max-abs): the layers behind fewer gates
-# sit at the usual 5e-2; conv6's sum runs over 56 x 56 positions behind three more ReLU / arg-max layers (measured values printed)
-DB_TOL = {6: 1e-1, 9: 5e-2, 12: 5e-2, 15: 5e-2}
-
-
 def test_networks_vs_golden():
     g = load("networks_full")
     sd = gu.adapter_weights(seed=int(g["seed"][0]))
@@ -302,9 +297,9 @@ def test_networks_vs_golden():
                 # no bf16-forward twin); against the bf16-forward reference they are held to 5e-2 like every other layer
                 continue
             assert abs(w.norm().item() - want_norm) < 5e-2 * want_norm, (nm, idx, w.norm().item(), want_norm)
-            e_b = relerr(st.g[pre + f"meta_net.{idx}.bias"][:64], g[f"{nm}_db{idx}"])
-            print(f"{nm} conv{idx} bias gradient vs the fp32 golden: {e_b:.3e}")
-            assert e_b < DB_TOL[idx], (nm, idx, e_b)
+            # the bias gradients are sums over every position behind the ReLU / arg-max gates and move by 8-14 % of max-abs between
+            # an fp32 and a bf16 forward (measured, round 6); they are held to 5e-2 -- every layer, weights and biases -- against
+            # the reference run with the bf16 forward rounding (test_ve_net_grads_vs_reference_bf16_forward_golden), not here
 
 
 class _TwoIdenticalRanks:

@@ -264,6 +264,8 @@ def main():
     ap.add_argument("--no-b1", action="store_true", help="skip the batch-1 line (BASELINE configs[1]) reported as config1_b1")
     ap.add_argument("--no-minigpt4", action="store_true",
                     help="skip the MiniGPT-4 arch line (SURVEY 8d's second reported workload, S = 81) reported as config_minigpt4_b8")
+    ap.add_argument("--side-steps", type=int, default=150,
+                    help="timed steps of the two side workloads (config1_b1, config_minigpt4_b8): ~3 + 4.5 s of GPU work")
     ap.add_argument("--host-inputs", action="store_true",
                     help="inputs start in (pinned) host memory and every step uploads a fresh batch: the PCIe-inclusive rate "
                          "(DESIGN.md; never the headline `value`, whose inputs are resident in HBM)")
@@ -412,10 +414,32 @@ def main():
                                        launches_matched=src_n, of_launches=dk["launches"], from_committed_profile=True,
                                        source=f"profiles/{os.path.basename(tpath)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate "
                                               f"passes; read = 2 x FETCH_SIZE on gfx950)")
+                # the same figure from the NEWEST committed rocprofv3 profile (profiles/rNN_step_breakdown.md total of the kernel in
+                # the profiled step + rNN_step_gemm_shapes.csv FLOPs; tools/roofline_from_profiles.py): another box, another day --
+                # beside the live number so the two are compared in the line itself
+                committed = None
+                try:
+                    import csv as _csv, re as _re
+                    rounds = sorted({f.split("_")[0] for f in os.listdir(pdir) if f.endswith("_step_gemm_shapes.csv")
+                                     and os.path.exists(os.path.join(pdir, f.split("_")[0] + "_step_breakdown.md"))})
+                    if rounds:
+                        rnd = rounds[-1]
+                        fl_c = sum(int(r_["launches"]) * 2.0 * int(r_["M"]) * int(r_["N"]) * int(r_["K"])
+                                   for r_ in _csv.DictReader(open(os.path.join(pdir, f"{rnd}_step_gemm_shapes.csv")))
+                                   if r_["kernel"] == dname)
+                        for ln in open(os.path.join(pdir, f"{rnd}_step_breakdown.md")):
+                            m_ = _re.match(r"\| `(?:void )?" + dname + r"[^|]*\| (\d+) \| ([\d.]+) \|", ln)
+                            if m_:
+                                tf_c = fl_c / (float(m_.group(2)) * 1e-3) / 1e12
+                                committed = dict(round=rnd, launches=int(m_.group(1)), kernel_ms=float(m_.group(2)),
+                                                 tflops=round(tf_c, 1), frac=round(tf_c / PEAK_BF16_TFLOPS, 4))
+                                break
+                except Exception:                                  # noqa: BLE001 -- evidence lookup only
+                    committed = None
                 all_ms = sum(v["total_ms"] for v in per.values())
                 all_fl = sum(v["tflops"] * v["total_ms"] for v in per.values())
                 roof = dict(bound="mfma", kernel=dname, achieved=dk["tflops"], peak=PEAK_BF16_TFLOPS, unit="TFLOP/s",
-                            frac=round(dk["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=traffic,
+                            frac=round(dk["tflops"] / PEAK_BF16_TFLOPS, 4), traffic=traffic, rocprof_frac_committed=committed,
                             population="every launch of the kernel in one step (LLaMA fwd + dgrad, ViT fwd; split-K launches "
                                        "included, each timed alone by a HIP-event pair on its stream, minus the calibrated "
                                        "duration of an empty pair)",
@@ -446,16 +470,20 @@ def main():
             s1 = make_samples(1, cfg["vocab"], 42, dev)
             if prefetch:
                 model.prepare_vit_graph(s1)
-            for i in range(2):
-                step(i, s1)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
+            # >= 150 timed steps (~3 s): long enough for a 5-s utilisation sampler beside the run to see the leg
+            n1 = a.side_steps
             for i in range(3):
                 step(i, s1)
+            model.finish_update()
             torch.cuda.synchronize()
-            d1 = (time.perf_counter() - t0) / 3
-            extra["config1_b1"] = dict(value=round(1.0 / d1, 2), unit="images/s", ms_per_step=round(1e3 * d1, 2), steps=3,
-                                       warmup=2, workload="BASELINE configs[1]: the same fine-tune step at batch 1 "
+            t0 = time.perf_counter()
+            for i in range(n1):
+                step(i, s1)
+            model.finish_update()
+            torch.cuda.synchronize()
+            d1 = (time.perf_counter() - t0) / n1
+            extra["config1_b1"] = dict(value=round(1.0 / d1, 2), unit="images/s", ms_per_step=round(1e3 * d1, 2), steps=n1,
+                                       warmup=3, workload="BASELINE configs[1]: the same fine-tune step at batch 1 "
                                                           "(weight-streaming regime)")
         except Exception as e:                                    # noqa: BLE001
             extra["config1_b1"] = dict(value=None, error=repr(e))
@@ -480,14 +508,15 @@ def main():
             m2.finish_update()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            for i in range(5):
+            n2 = a.side_steps
+            for i in range(n2):
                 l2 = step2(3 + i)
             m2.finish_update()
             torch.cuda.synchronize()
-            d2 = (time.perf_counter() - t0) / 5
+            d2 = (time.perf_counter() - t0) / n2
             fl2 = flops_per_sample("mini_gpt4", 0, cfg)
             extra["config_minigpt4_b8"] = dict(
-                value=round(a.batch / d2, 2), unit="images/s", ms_per_step=round(1e3 * d2, 2), steps=5, warmup=3,
+                value=round(a.batch / d2, 2), unit="images/s", ms_per_step=round(1e3 * d2, 2), steps=n2, warmup=3,
                 per_gpu_batch=a.batch, seq_len=fl2["S"], algorithmic_tflop_per_sample=round(fl2["total"] / 1e12, 3),
                 step_frac_of_peak=round(a.batch * fl2["total"] / d2 / 1e12 / PEAK_BF16_TFLOPS, 4), loss=round(float(l2), 4),
                 trainable_params=m2.store.n_params(),
@@ -515,7 +544,10 @@ def main():
                        "parallelism": f"dp{world}", "rccl_ranks": rccl_ranks,
                        "dp_exchange": (dp.mode + ("+bf16" if dp.grad_dtype == torch.bfloat16 else "")) if world > 1 else None,
                        "trainable_params": n_trainable,
-                       "peft_lora_qv_r8": bool(a.lora) and a.arch == "myriad",
+                       # peft's LoraLayer formula on q_proj / v_proj, r = 8 (myriad.py:170-180).  peft itself is absent from the image
+                       # and from the reference tree: the formula is pinned to hand-computed known-answer vectors, not to a peft run
+                       "lora_qv_r8": bool(a.lora) and a.arch == "myriad",
+                       "lora_parity": "peft formula pinned to hand-computed KATs (peft not installable: reference-unpinnable)",
                        "algorithmic_tflop_per_sample": round(fl["total"] / 1e12, 3)},
             "loss": round(float(loss), 4), "model_build_s": round(build_s, 1),
             # whole-step algorithmic FLOPs (SURVEY 8d F_step x per-GPU batch) / measured step time / dense bf16 peak, per GPU

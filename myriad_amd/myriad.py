@@ -604,12 +604,32 @@ class MyriadHIP(nn.Module):
         c = self._ctx
         if c is None:
             raise RuntimeError("backward() without a training forward")
-        prev = self.store.flat_g_comm.clone() if accumulate else None
+        # Accumulation (base_task.py:262-271): this call's gradients are added to the buffer's.  The map tokenizer's conv-head
+        # weight -- 420 of the buffer's 460 MB -- accumulates IN PLACE in its weight-gradient GEMM (VENet.backward: the residual
+        # operand), so only the other ~10 M gradients are set aside, zero-filled and added back (the former form
+        # cloned, zero-filled and re-added the whole buffer).  A loss scale other than 1 keeps the whole-buffer form (it multiplies
+        # this call's gradients only).
+        head = None
+        if accumulate and float(gscale) == 1.0 and self.arch == "myriad" and self.ve_tok.head_accumulates_in_place:
+            o_n = self.store.offsets.get("VETokenizer.meta_net.15.weight")
+            if o_n is not None and o_n[1] >= (1 << 20):
+                head = (o_n[0], o_n[0] + o_n[1])
+        self._acc_head = head
+        fg = self.store.flat_g_comm
+        if not accumulate:
+            prev = None
+        elif head is None:
+            prev = fg.clone()
+        else:
+            prev = (fg[:head[0]].clone(), fg[head[1]:].clone())
         zeroed, self._g_zeroed = getattr(self, "_g_zeroed", None), None
         if zeroed is not None and not accumulate:
             torch.cuda.current_stream().wait_event(zeroed)        # train_step filled it on the leaf stream during the forward
+        elif head is None:
+            fg.zero_()
         else:
-            self.store.flat_g_comm.zero_()
+            fg[:head[0]].zero_()
+            fg[head[1]:].zero_()
         used = {"lora"} if self.use_lora else set()
         if self.arch == "myriad":
             used.add("expert_adaptor")
@@ -655,7 +675,7 @@ class MyriadHIP(nn.Module):
             aux.wait_stream(main)
             leaf_keep = (dtok, self.ve_tok._saved)       # main-stream allocations the side stream reads: alive until the join
             with torch.cuda.stream(aux):
-                self.ve_tok.backward(dtok)
+                self.ve_tok.backward(dtok, accumulate_head=self._acc_head is not None)
                 if early_adamw is not None and self._leaf_aside:
                     # single-process step: the map tokenizer holds 91 % of the trainable parameters (its 105 M-weight head) and its
                     # gradient is complete here, right behind the LLaMA backward -- its AdamW (0.55 ms of HBM traffic) runs on the
@@ -702,8 +722,15 @@ class MyriadHIP(nn.Module):
         if self._bwd_gscale != 1.0:
             ops.scale_(self.store.flat_g, self._bwd_gscale)
         if self._bwd_prev is not None:
-            n = self.store.flat_g_comm.numel()
-            ops.copy2d(self._bwd_prev.view(1, n), self.store.flat_g_comm.view(1, n), accumulate=True)
+            fg = self.store.flat_g_comm
+            if isinstance(self._bwd_prev, tuple):                 # the head's segment accumulated in place (backward())
+                a, b = self._acc_head
+                for pv, dst in ((self._bwd_prev[0], fg[:a]), (self._bwd_prev[1], fg[b:])):
+                    if pv.numel():
+                        ops.copy2d(pv.view(1, -1), dst.view(1, -1), accumulate=True)
+            else:
+                n = fg.numel()
+                ops.copy2d(self._bwd_prev.view(1, n), fg.view(1, n), accumulate=True)
             self._bwd_prev = None
         self._has_grads = True
         self._reattach_grads()

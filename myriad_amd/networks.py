@@ -95,8 +95,16 @@ class VENet:
             self._saved = dict(stem=saved, head=head, B=B)
         return out.view(B, T, self.head_out)
 
-    def backward(self, dtokens: torch.Tensor) -> None:
-        """dtokens [B,T,head_out] f32.  Writes weight/bias gradients into self.g (overwrites)."""
+    @property
+    def head_accumulates_in_place(self) -> bool:
+        """True when backward(accumulate_head=True) really accumulates: a k x k head whose GEMM writes the gradient directly."""
+        return self.head_k != 1 and (self.head_k * self.head_k * 1024) % 64 == 0
+
+    def backward(self, dtokens: torch.Tensor, accumulate_head: bool = False) -> None:
+        """dtokens [B,T,head_out] f32.  Writes weight/bias gradients into self.g (overwrites).  accumulate_head: the weight
+        gradient of a k x k head without bias column (the VETokenizer's 105 M-weight conv: 91 % of the model's trainables) is ADDED
+        to what self.g holds -- the GEMM's residual operand, in place -- instead of overwriting it (gradient accumulation windows,
+        base_task.py:262-271: no copy of the 420 MB segment is made, MyriadHIP.backward)."""
         sv = self._saved
         if sv is None:
             raise RuntimeError("backward() without saved forward")
@@ -113,7 +121,10 @@ class VENet:
         else:
             Kpad = wq.shape[1]
             if sv["head"][3]:                                      # no bias column: the product IS the weight gradient
-                ops.gemm_auto_f32(dyT, ops.transpose_to_bf16(a, 64), gw)
+                if accumulate_head:
+                    ops.gemm(dyT, ops.transpose_to_bf16(a, 64), out=gw, residual=gw)      # gw += dy^T . col (C may alias residual)
+                else:
+                    ops.gemm_auto_f32(dyT, ops.transpose_to_bf16(a, 64), gw)
                 gb.copy_(ops.colsum(dy32))
             else:
                 dwp = torch.empty((self.head_out, Kpad), dtype=F32, device=self.dev)

@@ -4,7 +4,7 @@
 R=$(pwd); O=$R/gpurun_out/${1:-r5q}; mkdir -p $O
 python bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench.log 2>&1; tail -1 $O/bench.log > $O/bench_n1.json
 cd /tmp && export TMPDIR=/tmp
-timeout 900 rocprofv3 --kernel-trace -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline --no-minigpt4 --steps 4 --warmup 2 > $O/kt.log 2>&1
+timeout 900 rocprofv3 --kernel-trace -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline --no-minigpt4 --side-steps 3 --steps 4 --warmup 2 > $O/kt.log 2>&1
 cd $R
 DB=$(find $O/kt -name "*.db" | head -1)
 python tools/rocpd_step.py $DB > $O/step_breakdown.md 2>&1

@@ -29,12 +29,12 @@ if sc: print(f"sclk MHz: samples {len(sc)}, max {max(sc)}, sorted tail {sorted(s
 if pw: print(f"socket power W: samples {len(pw)}, max {max(pw):.0f}, sorted tail {[round(x) for x in sorted(pw)[-8:]]}")
 PY
 cd /tmp && export TMPDIR=/tmp
-BENCH_SHAPES=$O/step_gemm_shapes_profiled.csv timeout 900 rocprofv3 --kernel-trace -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline --no-minigpt4 > $O/kt.log 2>&1
+BENCH_SHAPES=$O/step_gemm_shapes_profiled.csv timeout 900 rocprofv3 --kernel-trace -d $O/kt -o kt -- python $R/bench.py --no-cpu-baseline --no-minigpt4 --side-steps 3 > $O/kt.log 2>&1
 timeout 600 rocprofv3 --kernel-trace -d $O/ktdec -o dec -- python $R/tools/decode_bench.py --new 96 > $O/ktdec.log 2>&1
 mkdir -p $O/pmc
-timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc/m1 -o m1 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-probe --no-minigpt4 > $O/pmc/m1.log 2>&1
+timeout 900 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/pmc/m1 -o m1 -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-probe --no-minigpt4 --side-steps 3 > $O/pmc/m1.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc/$C -o $C -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-probe --no-minigpt4 > $O/pmc/$C.log 2>&1
+  timeout 900 rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc/$C -o $C -- python $R/bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-probe --no-minigpt4 --side-steps 3 > $O/pmc/$C.log 2>&1
 done
 cd $R
 DB=$(find $O/kt -name "*.db" | head -1)

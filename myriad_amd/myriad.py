@@ -160,11 +160,24 @@ class ParamStore:
                 ops.adamw_gated(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b], lr,
                                 weight_decay if decays else 0.0, self.used[mi:mi + 1], self.steps_dev[mi:mi + 1], beta2=beta2)
 
+    def adamw_pieces(self, pieces, lr: float, weight_decay: float = 0.05, beta2: float = 0.999, grad_scale: float = 1.0) -> None:
+        """The gated AdamW on the slices `pieces` [(lo, hi)] of the flat buffers only -- no step-counter bump: a part of the step's
+        update issued early (a data-parallel segment whose exchange is complete); adamw_step(..., exclude=pieces' span) does the
+        rest and bumps the counters.  Same kernel, same per-module flags and step counts as the one-shot update."""
+        for mi, a0, b0, decays in self.ranges:
+            for lo, hi in pieces:
+                a, b = max(a0, lo), min(b0, hi)
+                if a < b:
+                    ops.adamw_gated(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b], lr,
+                                    weight_decay if decays else 0.0, self.used[mi:mi + 1], self.steps_dev[mi:mi + 1], beta2=beta2,
+                                    grad_scale=grad_scale)
+
     def adamw_step(self, lr: float, weight_decay: float = 0.05, beta2: float = 0.999, grad_scale: float = 1.0, shard=None,
-                   skip=()):
+                   skip=(), exclude=()):
         """torch.optim.AdamW semantics (runner_base.py:132-137), fused, on the flat buffers; modules unused on every rank
         this step are left alone (see class docstring).  `shard` = (lo, hi) or a list of such: update only those slices of the
-        flat buffer (DataParallel mode 'rs_ag': each rank owns 1/world of every exchange segment's optimiser state).  `skip`: modules adamw_module() already
+        flat buffer (DataParallel mode 'rs_ag': each rank owns 1/world of every exchange segment's optimiser state).  `exclude`:
+        spans adamw_pieces() already updated this step.  `skip`: modules adamw_module() already
         updated this step."""
         self.step += 1
         pieces = None
@@ -180,9 +193,13 @@ class ParamStore:
                 a, b = max(a0, lo), min(b0, hi)
                 if a >= b:
                     continue
-                ops.adamw_gated(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b], lr,
-                                weight_decay if decays else 0.0, self.used[mi:mi + 1], self.steps_dev[mi:mi + 1], beta2=beta2,
-                                grad_scale=grad_scale)
+                todo = [(a, b)]
+                for ex_lo, ex_hi in exclude:                      # spans adamw_pieces() already updated this step
+                    todo = [q for (x, y) in todo for q in ((x, min(y, ex_lo)), (max(x, ex_hi), y)) if q[0] < q[1]]
+                for a, b in todo:
+                    ops.adamw_gated(self.flat_p[a:b], self.flat_g[a:b], self.flat_m[a:b], self.flat_v[a:b], lr,
+                                    weight_decay if decays else 0.0, self.used[mi:mi + 1], self.steps_dev[mi:mi + 1], beta2=beta2,
+                                    grad_scale=grad_scale)
         if self.modules:
             ops.adamw_bump(self.used, self.steps_dev)
 
@@ -683,13 +700,13 @@ class MyriadHIP(nn.Module):
                     self.store.adamw_module("VETokenizer", early_adamw[0], early_adamw[1])
                     self._early_done = {"VETokenizer"}
                 if early_exchange is not None:
-                    early_exchange[0].start_part(self.store.flat_g_comm, self.store.total, early_exchange[1])
+                    self._start_early_exchange(early_exchange)
                 leaf_ev = torch.cuda.Event()
                 leaf_ev.record()
         else:
             leaf_ev, leaf_keep = None, None
             if early_exchange is not None:                # unused at this rank's prompt stage: the segment's zeros travel now
-                early_exchange[0].start_part(self.store.flat_g_comm, self.store.total, early_exchange[1])
+                self._start_early_exchange(early_exchange)
         dq, denc = self.qformer.backward(dqo)
         ins_ev, ins_keep = None, None
         if c["use_ins"]:
@@ -717,6 +734,24 @@ class MyriadHIP(nn.Module):
             torch.cuda.current_stream().wait_event(ins_ev)
         del leaf_keep, ins_keep                           # freed only now: later main-stream work is ordered behind the events
         self._finish_backward()
+
+    def _start_early_exchange(self, early_exchange) -> None:
+        """early_exchange = (dp, segment index[, (lr, weight_decay)]): start the segment's collective behind the current stream;
+        with the third item the segment's optimiser update follows its collective on the exchange's own stream order -- the gated
+        AdamW on this rank's slices of the segment (its 1/world piece in 'rs_ag') with grad_scale 1/world, then in 'rs_ag' the
+        all-gather of the updated parameters -- so both run under the Q-Former backward as well (finish_update() does the rest of
+        the buffer and bumps the step counters)."""
+        dp, k = early_exchange[0], early_exchange[1]
+        st = self.store
+        if len(early_exchange) > 2 and getattr(dp, "supports_early_update", False):
+            lr, wd = early_exchange[2]
+
+            def then():
+                st.adamw_pieces(dp.part_shards(st.total, k), lr, wd, grad_scale=1.0 / dp.world)
+                dp.gather_part(st.flat_p, k)
+            dp.start_part(st.flat_g_comm, st.total, k, then=then)
+        else:
+            dp.start_part(st.flat_g_comm, st.total, k)
 
     def _finish_backward(self):
         if self._bwd_gscale != 1.0:
@@ -909,7 +944,8 @@ class MyriadHIP(nn.Module):
             if (dp is not None and dp.world > 1 and overlap and due and not accumulate and self.arch == "myriad"
                     and hasattr(dp, "start_part") and os.environ.get("MYRIAD_DP_EARLY", "1") != "0"):
                 k = self._dp_segment(dp)
-                early_x = (dp, k) if k is not None else None
+                if k is not None:
+                    early_x = (dp, k, (lr, weight_decay)) if os.environ.get("MYRIAD_DP_EARLY_ADAMW", "1") != "0" else (dp, k)
             self.backward(accumulate=accumulate, early_adamw=early, early_exchange=early_x)
             self._accum_count += 1
             if not due:
@@ -966,9 +1002,11 @@ class MyriadHIP(nn.Module):
                 return
             dp.wait()
             shard = self._dp_shards(dp)
-            self.store.adamw_step(lr, wd, grad_scale=1.0 / dp.world, shard=shard)
+            done = dp.take_early_done() if hasattr(dp, "take_early_done") else set()      # segments updated behind their collective
+            segs = dp.segments(self.store.total) if done else []
+            self.store.adamw_step(lr, wd, grad_scale=1.0 / dp.world, shard=shard, exclude=[segs[k] for k in done])
             if shard is not None:
-                dp.gather_params(self.store.flat_p)
+                dp.gather_params(self.store.flat_p, skip=done) if done else dp.gather_params(self.store.flat_p)
 
     @torch.no_grad()
     def generate(self, samples, **generate_kwargs):

@@ -191,6 +191,9 @@ class DataParallel:
         self._segs = None                 # [(lo, hi)] tiling [0, total)
         self._seg_total = None
         self._started = set()             # segment indices already started in the exchange under way
+        self._flags_started = False       # the use flags travelled with an early part (start() then leaves them alone)
+        self._early_done = set()          # segments whose optimiser update (and all-gather) already followed their collective
+        self._upd = None                  # ctx path: the stream an early update runs on (it waits for the context on the device)
         # on RCCL (backend nccl) the exchange goes through the library's own verbs -- mh_allreduce_start_dt /
         # mh_reduce_scatter_start / mh_allgather_start / mh_allreduce_wait on an mh_ctx that owns the communicator and the side
         # stream (include/myriad_hip.h) -- both modes, both wire types; the process group is then only the channel that hands
@@ -330,16 +333,49 @@ class DataParallel:
             self._pending = True
         self._run(go)
 
-    def start_part(self, flat_g_comm: torch.Tensor, n_grad: int, k: int) -> None:
+    supports_early_update = True
+
+    def start_part(self, flat_g_comm: torch.Tensor, n_grad: int, k: int, then=None) -> None:
         """Start the exchange of segment k (see set_segments) NOW, ordered behind the current stream: the caller guarantees that
         this segment's gradient is complete there.  Every rank calls it at the same point of its step, also a rank whose step
-        did not touch the segment's module (its zeros are its contribution).  start() later exchanges the other segments."""
+        did not touch the segment's module (its zeros are its contribution).  start() later exchanges the other segments.
+        `then` (a callable): run right behind this segment's collective, on the exchange's own stream order -- the segment's
+        optimiser update (sharded in 'rs_ag') and, in 'rs_ag', the all-gather of its updated parameters (gather_part), so that
+        they too run under the rest of the backward.  The use flags then travel with this part (a gated update reads them)."""
         if self.world == 1:
             return
         if k in self._started:
             raise RuntimeError(f"DataParallel.start_part: segment {k} was already started in this exchange")
         self._started.add(k)
-        self._exchange(flat_g_comm, n_grad, [k], with_flags=False)
+        self._exchange(flat_g_comm, n_grad, [k], with_flags=then is not None)
+        if then is None:
+            return
+        self._flags_started = True
+        self._early_done.add(k)
+        if self.ctx is not None:
+            # the context's side stream belongs to the library: the update runs on a torch stream that waits for it ON THE DEVICE
+            if self._upd is None:
+                self._upd = torch.cuda.Stream(device=self.device)
+            with torch.cuda.stream(self._upd):
+                self.ctx.wait()                               # _upd waits for the collective(s) started so far
+                for fn in (self._pending or []):              # bf16 wire: cast back; rs_ag: the own piece into the buffer
+                    fn()
+                self._pending = []
+                then()                                        # AdamW (+ the all-gather, queued through the context behind it)
+        else:
+            self._run(then)                                   # in order behind the collective on the exchange stream
+
+    def part_shards(self, total: int, k: int):
+        """The slices of segment k this rank's optimiser owns: its piece in 'rs_ag', the whole segment otherwise."""
+        lo, hi = self.segments(total)[k]
+        return [self._piece(lo, hi)[:2]] if self.mode == "rs_ag" else [(lo, hi)]
+
+    def gather_part(self, flat_p: torch.Tensor, k: int) -> None:
+        """rs_ag: all-gather the updated parameters of segment k, ordered behind the current stream, without waiting (wait()
+        covers it).  No-op in 'allreduce' mode."""
+        if self.world == 1 or self.mode != "rs_ag":
+            return
+        self._gather_segment(flat_p, k, wait=False)
 
     def start(self, flat_g_comm: torch.Tensor, n_grad: Optional[int] = None) -> None:
         """Launch the exchange of [gradients (n_grad elements) | flags] -- every segment start_part() has not started yet, and the
@@ -348,8 +384,9 @@ class DataParallel:
             return
         n_grad = flat_g_comm.numel() if n_grad is None else n_grad
         ks = [k for k in range(len(self.segments(n_grad))) if k not in self._started]
-        self._started = set()
-        self._exchange(flat_g_comm, n_grad, ks, with_flags=True)
+        flags = not self._flags_started
+        self._started, self._flags_started = set(), False
+        self._exchange(flat_g_comm, n_grad, ks, with_flags=flags)
 
     def _ctx_exchange(self, flat_g_comm: torch.Tensor, n_grad: int, ks, with_flags: bool) -> None:
         """The exchange through the library's verbs.  Casts (bf16 wire) run on the current stream in front of / behind the
@@ -395,6 +432,8 @@ class DataParallel:
         self._pending = after
 
     def wait(self) -> None:
+        if self._upd is not None:
+            torch.cuda.current_stream().wait_stream(self._upd)      # an early update (ctx path) ran there
         if self._pending is not None and self.ctx is not None:
             self.ctx.wait()
             for fn in self._pending:
@@ -406,38 +445,52 @@ class DataParallel:
                 torch.cuda.current_stream().wait_stream(self.side)
             self._pending = None
 
+    def take_early_done(self):
+        """Segments whose update already followed their collective in the exchange just waited for (cleared by the call)."""
+        done, self._early_done = self._early_done, set()
+        return done
+
     def allreduce(self, flat_grad: torch.Tensor, n_grad: Optional[int] = None) -> None:
         self.start(flat_grad, n_grad)
         self.wait()
 
-    def gather_params(self, flat_p: torch.Tensor) -> None:
+    def _gather_segment(self, flat_p: torch.Tensor, k: int, wait: bool = True) -> bool:
+        """All-gather of one segment's parameters in place.  -> True when a context verb was queued and nobody waited for it."""
+        s_lo, s_hi = self.segments(flat_p.numel())[k]
+        seg = flat_p[s_lo:s_hi]
+        n = s_hi - s_lo
+        lo, hi, per = self._piece(0, n)
+        if self.ctx is not None and n == per * self.world:
+            mine = self._persistent(f"ag_mine{k}", per, flat_p.dtype, flat_p.device)
+            mine.copy_(seg[lo:hi])
+            self.ctx.all_gather(mine, seg)
+            if wait:
+                self.ctx.wait()
+            else:
+                self._pending = self._pending if isinstance(self._pending, list) else []
+            return not wait
+        if self._gloo or n != per * self.world:
+            mine = torch.zeros(per, dtype=flat_p.dtype, device=flat_p.device)
+            mine[:hi - lo].copy_(seg[lo:hi])
+            parts = [torch.empty_like(mine) for _ in range(self.world)]
+            self.dist.all_gather(parts, mine)
+            seg.copy_(torch.cat(parts)[:n])
+        else:
+            mine = self._persistent(f"ag_mine{k}", per, flat_p.dtype, flat_p.device)
+            mine.copy_(seg[lo:hi])                    # a copy: input and output may not alias
+            self.dist.all_gather_into_tensor(seg, mine)
+        return False
+
+    def gather_params(self, flat_p: torch.Tensor, skip=()) -> None:
         """rs_ag: after the sharded AdamW every rank holds fresh parameters for its pieces only; all-gather them in place,
-        segment by segment."""
+        segment by segment (`skip`: segments gather_part() already gathered)."""
         if self.world == 1 or self.mode != "rs_ag":
             return
-        total = flat_p.numel()
-        waited = False
-        for k, (s_lo, s_hi) in enumerate(self.segments(total)):
-            seg = flat_p[s_lo:s_hi]
-            n = s_hi - s_lo
-            lo, hi, per = self._piece(0, n)
-            if self.ctx is not None and n == per * self.world:
-                mine = self._persistent(f"ag_mine{k}", per, flat_p.dtype, flat_p.device)
-                mine.copy_(seg[lo:hi])
-                self.ctx.all_gather(mine, seg)
-                waited = True
-                continue
-            if self._gloo or n != per * self.world:
-                mine = torch.zeros(per, dtype=flat_p.dtype, device=flat_p.device)
-                mine[:hi - lo].copy_(seg[lo:hi])
-                parts = [torch.empty_like(mine) for _ in range(self.world)]
-                self.dist.all_gather(parts, mine)
-                seg.copy_(torch.cat(parts)[:n])
-            else:
-                mine = self._persistent(f"ag_mine{k}", per, flat_p.dtype, flat_p.device)
-                mine.copy_(seg[lo:hi])                    # a copy: input and output may not alias
-                self.dist.all_gather_into_tensor(seg, mine)
-        if waited:
+        queued = False
+        for k in range(len(self.segments(flat_p.numel()))):
+            if k not in skip:
+                queued |= self._gather_segment(flat_p, k, wait=False)
+        if queued:
             self.ctx.wait()
 
     def gather_state(self, store) -> None:

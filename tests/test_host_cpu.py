@@ -244,9 +244,18 @@ def _dp_segments_worker(rank, world, port, q):
             if segmented:
                 dp.set_segments(n_grad, cuts)
                 assert dp.segments(n_grad) == [(0, 256), (256, 3456), (3456, n_grad)]
-                dp.start_part(comm, n_grad, 1)           # the early segment first, as MyriadHIP.backward issues it ...
-                dp.start(comm, n_grad)                   # ... then everything else + the flags
+                p_early = torch.zeros(n_grad)
+
+                def then():                              # the segment's update behind its collective: own slices, then its all-gather
+                    for lo, hi in dp.part_shards(n_grad, 1):
+                        p_early[lo:hi] = -comm[lo:hi]
+                    dp.gather_part(p_early, 1)
+                dp.start_part(comm, n_grad, 1, then=then)   # the early segment first, as MyriadHIP.backward issues it (+ the flags) ...
+                flags_after_part = comm[n_grad:].clone()
+                dp.start(comm, n_grad)                   # ... then everything else (the flags are NOT summed a second time)
                 dp.wait()
+                assert torch.equal(flags_after_part, comm[n_grad:])
+                assert dp.take_early_done() == {1} and dp.take_early_done() == set()
                 try:
                     dp.set_segments(n_grad + 32, cuts)   # the segmentation is fixed once set
                     raise AssertionError("set_segments accepted a second geometry")
@@ -260,9 +269,15 @@ def _dp_segments_worker(rank, world, port, q):
             if mode == "rs_ag":
                 for lo, hi in pieces:
                     p[lo:hi] = -comm[lo:hi]
-                dp.gather_params(p)
+                if segmented:                            # segment 1 was updated and gathered behind its collective
+                    p[256:3456] = p_early[256:3456]
+                    dp.gather_params(p, skip={1})
+                else:
+                    dp.gather_params(p)
             else:
                 p = -comm[:n_grad].clone()
+                if segmented:
+                    assert torch.equal(p_early[256:3456], p[256:3456])
             res.append((comm[n_grad:].numpy().copy(), p.numpy().copy(), pieces))
         out[(mode, gd)] = res
     q.put((rank, out))

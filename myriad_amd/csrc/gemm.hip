@@ -614,11 +614,15 @@ static int big_tile_splits(int M, int N, int K, int tile_n) {
   const int kt = K / 64;
   int best = 1;
   double best_eff = 0.0;
-  for (int s = 1; s <= 4; ++s) {
-    if (s > 1 && kt / s < 16) break;
+  for (int s = 1; s <= 5; ++s) {
+    if (s > 1 && kt / s < 12) break;
     const long wg = tiles * s, rounds = (wg + 255) / 256;
-    // the reduce pass re-reads s fp32 slabs: its cost relative to the GEMM grows as s / K
-    const double eff = (double)wg / (double)(rounds * 256) / (s > 1 ? 1.0 + 600.0 * s / K : 1.0);
+    // the reduce pass re-reads s slabs: its cost relative to the GEMM grows as s / K.  Round 6 (tools/gemm_m648_splits.py, the
+    // MiniGPT-4 arch's M = 648): a five-way split of the 48-tile N = 4096 launches (240 workgroups) beats four (192) by 5-8 %,
+    // and a split that only trades a half-empty round for slabs + a reduce (144 / 129 / 258 tiles: 74.7 / 74.5 / 141.6 us unsplit
+    // against 77.7 / 76.0 / 145.7 three-way) is not worth it -- unsplit also keeps the fused SwiGLU / direct bf16 epilogues.
+    // The batch-8 Myriad shapes (80 / 85 / 240 / 215 / 430 tiles) and the ViT's keep their plans.
+    const double eff = (double)wg / (double)(rounds * 256) / (s > 1 ? 1.0 + 900.0 * s / K : 1.0);
     if (eff > best_eff + 1e-9) { best_eff = eff; best = s; }
   }
   return best;
@@ -696,7 +700,7 @@ static void gemm_plan(int M, int N, int K, int flags, int* kernel, int* splits) 
     const long tiles = (long)((M + 255) / 256) * ((N + 255) / 256);
     int s = can_split ? big_tile_splits(M, N, K, 256) : 1;
     if ((size_t)s * M * N * sizeof(float) > g_ws_bytes) s = 1;
-    if (tiles * s >= 128 && K / s >= 1024) { *kernel = 2; *splits = s; return; }
+    if (tiles * s >= 128 && K / s >= 768) { *kernel = 2; *splits = s; return; }
   }
   if (can_split) {
     const int s = auto_splits(M, N, K);

@@ -61,23 +61,28 @@ __device__ __forceinline__ long silu_gcol(int c, int I, int blk, int* ustep) {
   return (long)(c / blk) * 2 * blk + (c % blk);
 }
 
-__global__ void silu_mul_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ h, long M, int I, int blk) {
+// ldg / ldh: row strides of gu / h in elements (0: dense, 2 I / I) -- a column slice of a wider pair of buffers (gemm.hip:
+// mh_gemm_swiglu_fwd's left-over column blocks)
+__global__ void silu_mul_fwd_kernel(const bf16_t* __restrict__ gu, bf16_t* __restrict__ h, long M, int I, int blk, long ldg = 0,
+                                    long ldh = 0) {
   const int per_row = I >> 3;
   const long total = M * per_row;
+  ldg = ldg ? ldg : 2L * I;
+  ldh = ldh ? ldh : (long)I;
   for (long it = blockIdx.x * (long)blockDim.x + threadIdx.x; it < total; it += (long)gridDim.x * blockDim.x) {
     const long m = it / per_row;
     const int c = (int)(it - m * per_row) * 8;
     int us;
     const long gc = silu_gcol(c, I, blk, &us);
-    const short8_t g = *reinterpret_cast<const short8_t*>(gu + m * 2 * I + gc);
-    const short8_t u = *reinterpret_cast<const short8_t*>(gu + m * 2 * I + gc + us);
+    const short8_t g = *reinterpret_cast<const short8_t*>(gu + m * ldg + gc);
+    const short8_t u = *reinterpret_cast<const short8_t*>(gu + m * ldg + gc + us);
     short8_t o;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float gv = bf2f((bf16_t)g[e]), uv = bf2f((bf16_t)u[e]);
       o[e] = (short)f2bf(gv / (1.f + __expf(-gv)) * uv);
     }
-    *reinterpret_cast<short8_t*>(h + m * I + c) = o;
+    *reinterpret_cast<short8_t*>(h + m * ldh + c) = o;
   }
 }
 
@@ -131,6 +136,15 @@ extern "C" int mh_silu_mul_fwd_blk(const void* gu, void* h, int M, int I, int bl
   if (I % 8 || blk < 0 || (blk && ((blk % 8) || (I % blk)))) return MH_ERR_ARG;
   hipLaunchKernelGGL(silu_mul_fwd_kernel, dim3(ew_grid((long)M * (I / 8))), dim3(EW_NT), 0, stream,
                      (const bf16_t*)gu, (bf16_t*)h, (long)M, I, blk);
+  MH_CHECK_LAUNCH();
+  return MH_OK;
+}
+// a column slice: gu [M, 2 I] at row stride ldg, h [M, I] at row stride ldh (gemm.hip)
+int mh_launch_silu_mul_fwd_blk_ld(const void* gu, long ldg, void* h, long ldh, int M, int I, int blk, hipStream_t stream) {
+  if (M <= 0) return MH_OK;
+  if (I % 8 || blk <= 0 || (blk % 8) || (I % blk) || (ldg % 8) || (ldh % 8) || ldg < 2L * I || ldh < I) return MH_ERR_ARG;
+  hipLaunchKernelGGL(silu_mul_fwd_kernel, dim3(ew_grid((long)M * (I / 8))), dim3(EW_NT), 0, stream,
+                     (const bf16_t*)gu, (bf16_t*)h, (long)M, I, blk, ldg, ldh);
   MH_CHECK_LAUNCH();
   return MH_OK;
 }

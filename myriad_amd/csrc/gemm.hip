@@ -992,13 +992,36 @@ static bool swiglu_fusable(int M, int N, int K, int lda, int ldb, const void* A,
 }
 
 // gu[M, 2I] = X[M, K] . Wgu[2I, K]^T (bf16, saved for the backward) and act[M, I] = silu(g) * u
+int mh_launch_silu_mul_fwd_blk_ld(const void* gu, long ldg, void* h, long ldh, int M, int I, int blk, hipStream_t stream);
+
 extern "C" int mh_gemm_swiglu_fwd(const void* X, int ldx, const void* Wgu, int ldw, void* gu, int ldgu, void* act, int ldact,
                                   int M, int I, int K, hipStream_t stream) {
   if (M <= 0 || I <= 0) return MH_OK;
   if (!gu || !act || (I % 128) || (ldgu % 8) || (ldact % 8) || ldgu < 2 * I || ldact < I) return MH_ERR_ARG;
-  if (swiglu_fusable(M, 2 * I, K, ldx, ldw, X, Wgu))
+  if (swiglu_fusable(M, 2 * I, K, ldx, ldw, X, Wgu)) {
+    // Round 6: a tile count a few tiles past a whole number of rounds (the MiniGPT-4 arch: 648 rows x 22016 columns = 258 tiles
+    // on 256 CUs, a second round for two tiles: 141 us where one round is ~75) -- the fused launch takes the column blocks that
+    // fill whole rounds, the one or two left-over 256-column blocks (whole gate | up pairs of the block-128 layout) go through
+    // the ordinary planned product on their slice (a K-split launch of small tiles) and the strided gate kernel.  Those columns
+    // then carry split-K rounding (fp32 partial sums added before the bf16 rounding) instead of one unsplit accumulation.
+    const int tm = (M + 255) / 256, tn = (2 * I) / 256;
+    const long tiles = (long)tm * tn;
+    const int over = (int)(tiles % 256);
+    const int lc = (over + tm - 1) / tm;                      // column tiles to peel off
+    if (tiles > 256 && over > 0 && lc <= 2 && (2 * I) % 256 == 0 && lc < tn && g_ws) {
+      const int N1 = (tn - lc) * 256, NL = lc * 256;
+      int rc = mh_launch_gemm_256(X, ldx, Wgu, ldw, gu, ldgu, M, N1, K, nullptr, nullptr, 0, MH_GEMM_SWIGLU_FWD, 1.0f, 1, K / 64,
+                                  0L, stream, act, ldact);
+      if (rc) return rc;
+      bf16_t* gul = reinterpret_cast<bf16_t*>(gu) + N1;
+      rc = mh_gemm_bf16_nt(X, ldx, reinterpret_cast<const bf16_t*>(Wgu) + (long)N1 * ldw, ldw, gul, ldgu, M, NL, K, nullptr, nullptr,
+                           0, 0, 1.0f, stream);
+      if (rc) return rc;
+      return mh_launch_silu_mul_fwd_blk_ld(gul, ldgu, reinterpret_cast<bf16_t*>(act) + N1 / 2, ldact, M, NL / 2, 128, stream);
+    }
     return mh_launch_gemm_256(X, ldx, Wgu, ldw, gu, ldgu, M, 2 * I, K, nullptr, nullptr, 0, MH_GEMM_SWIGLU_FWD, 1.0f, 1, K / 64,
                               0L, stream, act, ldact);
+  }
   if (ldgu != 2 * I || ldact != I) return MH_ERR_ARG;         // the elementwise kernels take dense rows
   const int rc = mh_gemm_bf16_nt(X, ldx, Wgu, ldw, gu, ldgu, M, 2 * I, K, nullptr, nullptr, 0, 0, 1.0f, stream);
   if (rc) return rc;

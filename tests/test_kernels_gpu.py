@@ -585,7 +585,8 @@ def test_attention_online_softmax_spike():
     assert relerr(o.float(), ref) < 1.5e-2
 
 
-@pytest.mark.parametrize("M,I,K", [(1184, 11008, 4096), (300, 256, 128), (148, 1024, 512), (148, 11008, 4096), (257, 11008, 4096)])
+@pytest.mark.parametrize("M,I,K", [(1184, 11008, 4096), (300, 256, 128), (148, 1024, 512), (148, 11008, 4096), (257, 11008, 4096),
+                                   (648, 11008, 4096)])
 def test_swiglu_fused_into_the_mlp_gemms(M, I, K):
     """mh_gemm_swiglu_fwd/bwd (SiLU-gated product in the gate|up GEMM's epilogue, its backward in the down dgrad's) against
     an fp32 torch model of LlamaMLP (modeling_llama.py:139-140) and bit-for-bit against GEMM + silu kernels.  The fused
@@ -615,7 +616,15 @@ def _swiglu_case(M, I, K):
     assert relerr(gu3[:, :, 0].reshape(M, I), g_ref) < 6e-3 and relerr(gu3[:, :, 1].reshape(M, I), u_ref) < 6e-3
     assert relerr(act.float(), F.silu(g_ref) * u_ref) < 1.5e-2
     gu2 = ops.gemm(x, wgu)
-    assert torch.equal(gu, gu2) and torch.equal(act, ops.silu_mul_fwd_blk(gu2))
+    if (M, I) == (648, 11008):
+        # 258 tiles on 256 CUs (the MiniGPT-4 arch): the fused launch takes the 85 column blocks that fill one round, the left-over
+        # 256 columns (one gate | up pair of blocks) go through a K-split product on their slice: bit-equal where fused, split-K
+        # rounding (fp32 partial sums, one bf16 rounding) on the slice, and the gate is applied to the pre-activations as stored
+        n1 = 85 * 256
+        assert torch.equal(gu[:, :n1], gu2[:, :n1]) and relerr(gu[:, n1:].float(), gu2[:, n1:].float()) < 4e-3
+        assert torch.equal(act, ops.silu_mul_fwd_blk(gu))
+    else:
+        assert torch.equal(gu, gu2) and torch.equal(act, ops.silu_mul_fwd_blk(gu2))
     # backward: dh [M, D] against the down projection's transposed weight [I, D]
     D = 256 if K <= 512 else 4096
     dh = bf(rnd(M, D, seed=74, scale=0.1)).to(DEV)
